@@ -1,0 +1,216 @@
+/*
+ * orbx.h -- C ABI of the MI355X-native ORB front-end (liborbx.so).
+ *
+ * The reference has no FFI: the path sits behind two plain C++ classes,
+ * ORB_SLAM2::ORBextractor (include/ORBextractor.h:74-282) and ORB_SLAM2::ORBmatcher
+ * (include/ORBmatcher.h:56-330), plus the Frame helpers the matchers call
+ * (src/Frame.cc:230-245, 327-392, 466-549).  Each entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no exceptions cross the boundary.
+ *
+ * Conventions
+ *  - every function returns an orbx_status (0 = ok) unless it is a pure scalar helper;
+ *  - "host" entry points take host pointers and are synchronous;
+ *  - "*_device" entry points take device pointers (HBM resident), enqueue on the given
+ *    hipStream_t (passed as void*, NULL = the context's own stream) and do not synchronise;
+ *  - a context (extractor / matcher) owns one HIP stream and its workspace; distinct contexts
+ *    may be used concurrently from different host threads, one context is not re-entrant
+ *    (same rule as the reference: src/Frame.cc:78-81 runs two extractor instances in two threads).
+ */
+#ifndef ORBX_H
+#define ORBX_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum orbx_status {
+    ORBX_OK = 0,
+    ORBX_ERR_BAD_ARG = 1,
+    ORBX_ERR_UNSUPPORTED_GEOMETRY = 2, /* the reference divides by zero for this image size (src/ORBextractor.cc:542-544, 783-786) or the size exceeds the packed-coordinate range */
+    ORBX_ERR_HIP = 3,
+    ORBX_ERR_CAPACITY = 4,             /* caller's output capacity too small */
+    ORBX_ERR_NO_DEVICE = 5
+} orbx_status;
+
+const char* orbx_status_string(int status);
+const char* orbx_last_error(void);     /* thread-local text of the last failure */
+
+/* Constructor arguments of ORBextractor (include/ORBextractor.h:83-84) plus one knob for the
+ * OpenCV build the caller wants to match. */
+typedef struct orbx_params {
+    int32_t nfeatures;
+    float   scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t blur_rounding; /* 0: generic C++ column pass, (sum+32768)>>16.  1: x86 SIMD column pass of OpenCV <= 3.4.0 (exact value rounded half-to-even for x < (w & ~3), generic for the last w%4 columns) */
+} orbx_params;
+
+/* Binary layout of cv::KeyPoint: pt.x, pt.y, size, angle, response, octave, class_id (28 bytes). */
+typedef struct orbx_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbx_keypoint;
+
+typedef struct orbx_best2 { int32_t best, best_idx, second, pad; } orbx_best2;
+
+/* ------------------------------------------------------------------------------------------ */
+/* Extractor: replaces ORBextractor (src/ORBextractor.cc:409-469 ctor, :1042-1104 operator()) */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct orbx_extractor orbx_extractor;
+
+/* A context is bound to one image size and a maximum batch (frames per launch).  The C++ drop-in
+ * class re-creates it when the image size changes.  device < 0: current device. */
+int orbx_extractor_create(const orbx_params* p, int width, int height, int max_batch, int device,
+                          orbx_extractor** out);
+void orbx_extractor_destroy(orbx_extractor* ex);
+
+/* Host-only tables; valid without a GPU.  GetScaleFactors / GetInverseScaleFactors /
+ * GetScaleSigmaSquares / GetInverseScaleSigmaSquares (include/ORBextractor.h:121-143),
+ * mnFeaturesPerLevel and umax (src/ORBextractor.cc:434-468).  Any pointer may be NULL. */
+int orbx_scale_tables(const orbx_params* p, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                      int32_t* features_per_level, int32_t* umax16);
+/* Level size as ComputePyramid derives it (src/ORBextractor.cc:1110-1111). */
+int orbx_level_size(const orbx_params* p, int width, int height, int level, int* w, int* h);
+/* Upper bound of keypoints one frame can return (quota + 3 per level: the quadtree can overshoot). */
+int orbx_keypoint_capacity(const orbx_params* p, int width, int height);
+
+/* ORBextractor::operator() for one host image.  kps/desc sized cap (desc: cap x 32 bytes). */
+int orbx_extract(orbx_extractor* ex, const uint8_t* image, ptrdiff_t stride,
+                 orbx_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* The same for n_frames host images (uploaded, processed as one batch, downloaded). */
+int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                       int n_frames, orbx_keypoint* kps, uint8_t* desc, int32_t* counts, int cap_per_frame);
+/* Device-resident batch: images, keypoints, descriptors and counts all in HBM; asynchronous. */
+int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdiff_t row_stride,
+                              ptrdiff_t frame_stride, int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc,
+                              int32_t* d_counts, int cap_per_frame, void* stream);
+
+/* mvImagePyramid[level] of frame `frame` of the last batch (include/ORBextractor.h:150): the padded
+ * (w+38) x (h+38) buffer is copied to dst (host); the image ROI starts at row 19, column 19. */
+int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride);
+/* Device view of the same level: pointer to the ROI origin and its row stride (border readable at
+ * negative offsets down to -19). */
+int orbx_pyramid_level_device(orbx_extractor* ex, int frame, int level, const uint8_t** d_roi,
+                              int* w, int* h, ptrdiff_t* stride);
+
+/* Parity taps on the last batch.  Candidates handed to DistributeOctTree (src/ORBextractor.cc:817-825),
+ * in the reference's order; packed as x<<20 | y<<8 | score with x,y relative to minBorder (16). */
+int orbx_debug_candidates(orbx_extractor* ex, int frame, int level, uint32_t* packed, int cap, int* n);
+/* Keypoints chosen by DistributeOctTree for one level, list order, same packing. */
+int orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, uint32_t* packed, int cap, int* n);
+
+/* DistributeOctTree on its own (src/ORBextractor.cc:538-762): host arrays in, device kernel, host out.
+ * keys packed as above; out receives the selected keys in list order. */
+int orbx_distribute_octree(int device, const uint32_t* packed_keys, int n, int minX, int maxX, int minY, int maxY,
+                           int N, uint32_t* out, int cap, int* n_out);
+
+/* Per-stage device time of the last batch, measured with HIP events on the launch stream when
+ * profiling is switched on (no counterpart in the reference).  Stage order: ORBX_STAGE_*. */
+enum { ORBX_STAGE_PYRAMID = 0, ORBX_STAGE_FAST = 1, ORBX_STAGE_OCTREE = 2, ORBX_STAGE_DESCRIBE = 3, ORBX_STAGE_COUNT = 4 };
+int orbx_extractor_set_profiling(orbx_extractor* ex, int on);
+int orbx_extractor_stage_ms(orbx_extractor* ex, float* ms /* ORBX_STAGE_COUNT */);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Matcher: replaces the Hamming loops of ORBmatcher (src/ORBmatcher.cc)                       */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct orbx_matcher orbx_matcher;
+int orbx_matcher_create(int device, orbx_matcher** out);
+void orbx_matcher_destroy(orbx_matcher* m);
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1650-1666): static and pure, host scalar. */
+int orbx_descriptor_distance(const uint8_t* a, const uint8_t* b);
+/* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1604-1645). */
+void orbx_compute_three_maxima(const int32_t* sizes, int L, int* ind1, int* ind2, int* ind3);
+
+/* Best / second-best Hamming distance of every query over a whole descriptor set, with the
+ * sequential loop's semantics (strict '<': lowest index wins ties; start values 256 / -1 / 256),
+ * i.e. the inner loop of every Search* routine (e.g. src/ORBmatcher.cc:439-460) without a window. */
+int orbx_hamming_best2(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int64_t nt, orbx_best2* out);
+int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
+                              int64_t index_base, orbx_best2* d_out, void* stream);
+/* Merge per-shard results (ranks x nq records, shard-major; best_idx already global) into nq records:
+ * the step after the RCCL all-gather when the map is sharded over GPUs. */
+int orbx_best2_merge_device(orbx_matcher* m, const orbx_best2* d_parts, int n_parts, int nq, orbx_best2* d_out, void* stream);
+/* Bytes of scratch the brute-force kernel keeps per call, for sizing checks. */
+int64_t orbx_hamming_best2_workspace_bytes(int nq, int64_t nt);
+
+/* Windowed form: distances of query i to candidates cand[rowptr[i] .. rowptr[i+1]) (CSR), for the
+ * order-dependent routines whose claim pass stays sequential on the host. */
+int orbx_hamming_csr(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                     const int32_t* rowptr, const int32_t* cand, int32_t* dist_out);
+
+/* Frame::AssignFeaturesToGrid / GetFeaturesInArea (src/Frame.cc:230-245, 327-392) on plain arrays. */
+typedef struct orbx_frame_grid orbx_frame_grid;
+int orbx_grid_create(const orbx_keypoint* kps, int n, float minX, float maxX, float minY, float maxY, orbx_frame_grid** out);
+void orbx_grid_destroy(orbx_frame_grid* g);
+int orbx_grid_features_in_area(const orbx_frame_grid* g, float x, float y, float r, int minLevel, int maxLevel,
+                               int32_t* out, int cap, int* n);
+
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:408-523) on plain arrays: frame bounds are
+ * Frame::mnMinX.. (src/Frame.cc:457-463); prev_matched_xy is vbPrevMatched (updated); matches12 is
+ * vnMatches12; *nmatches is the return value. */
+int orbx_search_for_initialization(orbx_matcher* m,
+                                   const orbx_keypoint* k1, const uint8_t* d1, int n1,
+                                   const orbx_keypoint* k2, const uint8_t* d2, int n2,
+                                   float minX, float maxX, float minY, float maxY,
+                                   float* prev_matched_xy, int window, float nnratio, int check_ori,
+                                   int32_t* matches12, int* nmatches);
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), candidate loop and acceptance
+ * (src/ORBmatcher.cc:68-125).  Query i = one visible map point: projection (qu,qv), search radius
+ * qr = r*scale[level] (:69), right-image projection qur (:93), predicted level, descriptor.
+ * claimed[n2]: -1 free, >=0 taken (stands for F.mvpMapPoints[idx] with observations, :87-89); a match
+ * stores the query index (:123). */
+int orbx_search_by_projection_mappoints(orbx_matcher* m,
+                                        const float* qu, const float* qv, const float* qr, const float* qur,
+                                        const int32_t* qlevel, const uint8_t* qdesc, int nq,
+                                        const orbx_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
+                                        float minX, float maxX, float minY, float maxY,
+                                        float nnratio, int32_t* claimed, int* nmatches);
+
+/* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (src/ORBmatcher.cc:1381-1470) and the
+ * KeyFrame form (:1531-1598): best-1 within th_dist (TH_HIGH=100 or ORBdist), rotation histogram.
+ * mode 0: levels octave-1..octave+1, 1: forward (>= octave), 2: backward (0..octave). */
+int orbx_search_by_projection_lastframe(orbx_matcher* m,
+                                        const float* qu, const float* qv, const float* qradius, const float* qur,
+                                        const int32_t* qoctave, const float* qangle, const uint8_t* qdesc, int nq,
+                                        const orbx_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
+                                        float minX, float maxX, float minY, float maxY,
+                                        int mode, int th_dist, int check_ori, int32_t* claimed, int* nmatches);
+
+/* Frame::ComputeStereoMatches, Hamming part (src/Frame.cc:466-549): per left keypoint the best right
+ * keypoint in its row band (start value TH_HIGH=100, index 0); best_dist = -1 marks a left keypoint the
+ * reference skips before the loop (:513-520). */
+int orbx_stereo_match(orbx_matcher* m,
+                      const orbx_keypoint* kl, const uint8_t* dl, int nl,
+                      const orbx_keypoint* kr, const uint8_t* dr, int nr,
+                      const float* scale_factors, int nlevels, int n_rows, float min_d, float max_d,
+                      int32_t* best_dist, int32_t* best_idx);
+/* Device-resident batch of stereo pairs straight from two orbx_extract_batch_device outputs. */
+int orbx_stereo_match_batch_device(orbx_matcher* m,
+                                   const orbx_keypoint* d_kl, const uint8_t* d_dl, const int32_t* d_nl,
+                                   const orbx_keypoint* d_kr, const uint8_t* d_dr, const int32_t* d_nr,
+                                   int cap_per_frame, int n_pairs,
+                                   const float* scale_factors, int nlevels, int n_rows, float min_d, float max_d,
+                                   int32_t* d_best_dist, int32_t* d_best_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Synthetic inputs for benchmarks and tests (no counterpart in the reference)                 */
+/* ------------------------------------------------------------------------------------------ */
+/* Frame generator: PCG32 seeded 0x5EED0000 + frame_index; W*H/200 random rectangles (side 6..48,
+ * intensity 16..240) painted in order over mid-grey, then uniform noise in [-6,6]. */
+void orbx_synth_frame(uint32_t frame_index, int w, int h, uint8_t* out, ptrdiff_t stride);
+/* Stereo pair: the right image paints every rectangle shifted left by its own disparity 0..40. */
+void orbx_synth_stereo(uint32_t frame_index, int w, int h, uint8_t* left, uint8_t* right, ptrdiff_t stride);
+/* n iid uniform 256-bit descriptors from PCG32(seed). */
+void orbx_synth_descriptors(uint32_t seed, int64_t n, uint8_t* out);
+/* nq queries: map rows picked by PCG32(seed) with Binomial(256, 0.08) bit flips; src_idx receives the rows. */
+void orbx_synth_queries(uint32_t seed, const uint8_t* map, int64_t n_map, int nq, uint8_t* out, int64_t* src_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

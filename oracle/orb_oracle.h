@@ -1,0 +1,128 @@
+/*
+ * orb_oracle.h -- CPU oracle for the ORB front-end hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A dependency-free C restatement of the reference's ORBextractor::operator(),
+ * ORBmatcher descriptor matching and the Frame helpers those use, written from
+ *   /root/reference/src/ORBextractor.cc, src/ORBmatcher.cc, src/Frame.cc
+ * plus the OpenCV 2.4.9-3.4.0 generic (non-IPP, non-OpenCL) semantics of the
+ * primitives the reference calls (resize INTER_LINEAR, copyMakeBorder
+ * REFLECT_101, FAST 9_16 with NMS, GaussianBlur 7x7 sigma 2, fastAtan2, cvRound).
+ *
+ * PARITY UNPINNED at the OpenCV boundary: the reference ships no tests, golden
+ * vectors or fixtures for this path and OpenCV is neither vendored in the
+ * reference nor installed in this image, so the primitives are pinned only by
+ * hand-derived known-answer values (quotas, umax, level sizes, scale tables,
+ * Gaussian taps, hand-computed FAST scores).  The oracle is the checker for the
+ * HIP library; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it.  The product library never links or calls it.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_params {
+    int32_t nfeatures;
+    float   scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t blur_rounding; /* 0 = (sum+32768)>>16 everywhere; 1 = x86 SIMD column pass (ties to even for x < w&~3) */
+} orc_params;
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct orc_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+typedef struct orc_best2 { int32_t best, best_idx, second, pad; } orc_best2;
+
+typedef struct orc_extractor orc_extractor;
+
+/* ---- primitives (OpenCV semantics) ---- */
+int   orc_cv_round(double v);
+float orc_fast_atan2(float y, float x);
+void  orc_resize_linear_u8(const uint8_t* src, int sw, int sh, ptrdiff_t sstride,
+                           uint8_t* dst, int dw, int dh, ptrdiff_t dstride);
+/* fills the `pad`-pixel frame around the w x h ROI at roi (buffer stride `stride`) by REFLECT_101 of the ROI */
+void  orc_border101(uint8_t* roi, int w, int h, ptrdiff_t stride, int pad);
+/* FAST-9_16 on a w x h sub-image; returns count; out arrays (x,y cell-local, score) sized cap */
+int   orc_fast9(const uint8_t* img, int w, int h, ptrdiff_t stride, int threshold, int nonmax,
+                int16_t* ox, int16_t* oy, uint8_t* oscore, int cap);
+int   orc_fast9_score(const uint8_t* center, ptrdiff_t stride, int threshold);
+void  orc_gauss7(const uint8_t* src, int w, int h, ptrdiff_t sstride, uint8_t* dst, ptrdiff_t dstride, int rounding);
+void  orc_gauss_taps(int32_t taps[7]);
+
+/* ---- extractor ---- */
+orc_extractor* orc_extractor_create(const orc_params* p);
+void  orc_extractor_destroy(orc_extractor* ex);
+int   orc_extractor_tables(const orc_extractor* ex, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                           int32_t* features_per_level, int32_t* umax16);
+/* returns 0 ok; 2 = geometry the reference cannot process (divide-by-zero cases); 4 = cap too small */
+int   orc_extract(orc_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t stride,
+                  orc_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* observable intermediates of the last orc_extract call */
+int   orc_level_size(const orc_extractor* ex, int level, int* w, int* h);
+/* pointer to the padded buffer of a level: (w+38) x (h+38), stride w+38; ROI starts at +19,+19 */
+const uint8_t* orc_level_padded(const orc_extractor* ex, int level, int* pw, int* ph);
+const uint8_t* orc_level_blurred(const orc_extractor* ex, int level); /* w x h, stride w; NULL if level had no keypoints */
+/* candidates handed to DistributeOctTree (coords relative to minBorder), in reference order */
+int   orc_level_candidates(const orc_extractor* ex, int level, int16_t* x, int16_t* y, uint8_t* score, int cap);
+/* keypoints of one level after distribution + orientation (level coordinates, before pt*=scale) */
+int   orc_level_keypoints(const orc_extractor* ex, int level, orc_keypoint* kps, int cap);
+
+/* DistributeOctTree on its own (src/ORBextractor.cc:538-762). keys: x,y relative to (minX,minY); returns count */
+int   orc_distribute_octree(const int16_t* x, const int16_t* y, const uint8_t* score, int n,
+                            int minX, int maxX, int minY, int maxY, int N,
+                            int32_t* out_index, int cap);
+
+/* ---- matcher ---- */
+int   orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void  orc_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int64_t nt, orc_best2* out);
+void  orc_compute_three_maxima(const int32_t* sizes, int L, int* ind1, int* ind2, int* ind3);
+
+typedef struct orc_frame_grid orc_frame_grid; /* 64x48 grid of Frame (src/Frame.cc:230-245, 327-392) */
+orc_frame_grid* orc_grid_create(const orc_keypoint* kps, int n, float minX, float maxX, float minY, float maxY);
+void  orc_grid_destroy(orc_frame_grid* g);
+int   orc_grid_features_in_area(const orc_frame_grid* g, float x, float y, float r, int minLevel, int maxLevel,
+                                int32_t* out, int cap);
+
+int   orc_search_for_initialization(const orc_keypoint* k1, const uint8_t* d1, int n1,
+                                    const orc_keypoint* k2, const uint8_t* d2, int n2,
+                                    float minX, float maxX, float minY, float maxY,
+                                    float* prev_matched_xy /* n1 x 2, in/out */, int window,
+                                    float nnratio, int check_ori, int32_t* matches12 /* n1 */);
+
+/* SearchByProjection(Frame, vector<MapPoint*>) inner part, src/ORBmatcher.cc:45-129, on plain arrays.
+ * query i: projected (u,v), radius already multiplied by scale, predicted level, descriptor,
+ * right-image u (proj_ur) used only when the frame key has u_right > 0. claimed[] (n2) is updated in place. */
+int   orc_search_by_projection_mappoints(const float* qu, const float* qv, const float* qr, const float* qur,
+                                         const int32_t* qlevel, const uint8_t* qdesc, int nq,
+                                         const orc_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
+                                         float minX, float maxX, float minY, float maxY,
+                                         float nnratio, int32_t* claimed /* n2: -1 free, else query idx */);
+
+/* SearchByProjection(Frame, LastFrame) inner part, src/ORBmatcher.cc:1381-1470: best-1, TH_HIGH, rot-hist.
+ * mode: 0 = both neighbours (level-1..level+1), 1 = forward (>= level), 2 = backward (0..level) */
+int   orc_search_by_projection_lastframe(const float* qu, const float* qv, const float* qradius, const float* qur,
+                                         const int32_t* qoctave, const float* qangle, const uint8_t* qdesc, int nq,
+                                         const orc_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
+                                         float minX, float maxX, float minY, float maxY,
+                                         int mode, int th_dist, int check_ori, int32_t* claimed);
+
+/* Frame::ComputeStereoMatches Hamming part, src/Frame.cc:466-549. best_dist/best_idx per left keypoint
+ * (best_dist = 100 and idx = 0 when nothing beat the start value; -1 marks "skipped" queries). */
+void  orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
+                       const orc_keypoint* kr, const uint8_t* dr, int nr,
+                       const float* scale_factors, int nlevels, int n_rows,
+                       float min_d, float max_d, int32_t* best_dist, int32_t* best_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

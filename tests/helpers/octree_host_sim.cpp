@@ -1,0 +1,22 @@
+// Single-thread host build of the level-synchronous quadtree (octree_algo.h) for CPU unit tests:
+// the HIP kernel runs the same source with one workgroup per (frame, level).
+#define ORBX_OCTREE_HOST_SIM 1
+#include "../../visual-slam_amd/csrc/octree_algo.h"
+#include <vector>
+#include <cmath>
+using namespace orbx;
+
+extern "C" int otsim_distribute(const uint32_t* keys, int nk, int minX, int maxX, int minY, int maxY, int N,
+                                uint32_t* out, int cap)
+{
+    const int W = maxX - minX, H = maxY - minY;
+    const int nIni = (int)std::round((float)W / H);
+    if (nIni <= 0) return -2;
+    const float hX = (float)W / nIni;
+    int NC = std::max(N + 3, 4 * nIni) + 1;
+    std::vector<OtNode> a(NC), b(NC);
+    std::vector<int32_t> cc(4 * NC), candPos(NC), pi(NC), cByPi(NC), keep(NC), posToCand(NC), scal(16), tmp(8);
+    std::vector<uint16_t> nodeOf(nk > 0 ? nk : 1);
+    OtShared s{a.data(), b.data(), cc.data(), candPos.data(), pi.data(), cByPi.data(), keep.data(), posToCand.data(), scal.data(), tmp.data()};
+    return ot_distribute(s, keys, nodeOf.data(), nk, W, H, nIni, hX, N, out, cap);
+}

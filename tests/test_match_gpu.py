@@ -1,0 +1,175 @@
+"""GPU parity: the HIP matcher (through the C ABI) against the CPU oracle.  Integer results: bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher(vsa):
+    m = vsa.Matcher(device=0)
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def stereo_features(vsa, oracle):
+    """Keypoints/descriptors of a synthetic stereo pair, extracted by the ORACLE (independent of the GPU extractor)."""
+    w, h = 752, 480
+    left, right = vsa.synth_stereo(3, w, h)
+    oex = oracle.Extractor(oracle.make_params())
+    kl, dl = oex.extract(left)
+    kr, dr = oex.extract(right)
+    return w, h, kl, dl, kr, dr
+
+
+def eq_best2(a, b):
+    return all(np.array_equal(a[f], b[f]) for f in ("best", "best_idx", "second"))
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (7, 300), (64, 5000), (513, 20000), (1000, 257), (4096, 70000)])
+def test_best2_random(vsa, oracle, matcher, nq, nt):
+    table = vsa.synth_descriptors(1000 + nt, nt)
+    q, _ = vsa.synth_queries(7 + nq, table, nq)
+    assert eq_best2(matcher.hamming_best2(q, table), oracle.hamming_best2(q, table))
+
+
+def test_best2_ties_and_extremes(vsa, oracle, matcher):
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+    table = np.concatenate([base, base, base[::-1], ~base])          # exact duplicates: lowest index must win
+    q = np.concatenate([base[:20], ~base[:5], np.zeros((1, 32), np.uint8)])
+    got, want = matcher.hamming_best2(q, table), oracle.hamming_best2(q, table)
+    assert eq_best2(got, want)
+    assert (got["best"][:20] == 0).all() and (got["second"][:20] == 0).all()
+    # a table holding only the complement of the query: distance 256 never beats the start value
+    one = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    got = matcher.hamming_best2(one, ~one)
+    assert got["best"][0] == 256 and got["best_idx"][0] == -1 and got["second"][0] == 256
+    assert eq_best2(got, oracle.hamming_best2(one, ~one))
+
+
+def test_best2_empty_table(vsa, matcher):
+    q = vsa.synth_descriptors(1, 5)
+    got = matcher.hamming_best2(q, np.zeros((0, 32), np.uint8))
+    assert (got["best"] == 256).all() and (got["best_idx"] == -1).all() and (got["second"] == 256).all()
+
+
+def test_best2_large_property(vsa, oracle, matcher):
+    """2^20 rows: every query is a corrupted copy of a known row; spot-check a slice against the oracle."""
+    nt, nq = 1 << 20, 512
+    table = vsa.synth_descriptors(42, nt)
+    q, src = vsa.synth_queries(43, table, nq)
+    got = matcher.hamming_best2(q, table)
+    d_src = np.array([oracle.descriptor_distance(q[i], table[src[i]]) for i in range(nq)])
+    assert (got["best"] <= d_src).all()
+    assert (got["best_idx"] == src).mean() > 0.99
+    assert (got["second"] >= got["best"]).all()
+    want = oracle.hamming_best2(q[:8], table)
+    assert eq_best2(got[:8], want)
+
+
+def test_csr_distances(vsa, oracle, matcher):
+    rng = np.random.default_rng(3)
+    t = vsa.synth_descriptors(5, 900)
+    q = vsa.synth_descriptors(6, 300)
+    lens = rng.integers(0, 90, 300); lens[::17] = 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cand = rng.integers(0, 900, rowptr[-1]).astype(np.int32)
+    dist = matcher.hamming_csr(q, t, rowptr, cand)
+    want = np.array([oracle.descriptor_distance(q[i], t[c]) for i in range(300) for c in cand[rowptr[i]:rowptr[i + 1]]], np.int32)
+    assert np.array_equal(dist, want)
+
+
+def test_search_for_initialization(vsa, oracle, matcher, stereo_features):
+    w, h, kl, dl, kr, dr = stereo_features
+    bounds = (0.0, float(w), 0.0, float(h))
+    prev = np.stack([kl["x"], kl["y"]], 1).astype(np.float32)
+    for check_ori in (True, False):
+        for window, ratio in ((100, 0.9), (40, 0.8), (300, 1.0)):
+            g = matcher.search_for_initialization(kl, dl, kr, dr, bounds, prev, window, ratio, check_ori)
+            o = oracle.search_for_initialization(kl, dl, kr, dr, bounds, prev, window, ratio, check_ori)
+            assert g[1] == o[1] and np.array_equal(g[0], o[0]) and np.array_equal(g[2], o[2])
+    assert o[1] >= 0
+    g = matcher.search_for_initialization(kl, dl, kr, dr, bounds, prev, 100, 0.9, True)
+    assert g[1] > 20 and (g[0] >= 0).sum() == g[1]
+
+
+def test_search_by_projection_variants(vsa, oracle, matcher, stereo_features):
+    w, h, kl, dl, kr, dr = stereo_features
+    rng = np.random.default_rng(9)
+    bounds = (0.0, float(w), 0.0, float(h))
+    scale = vsa.scale_tables(vsa.make_params())["scale"]
+    nq = len(kl)
+    qu = kl["x"] - rng.uniform(0, 30, nq).astype(np.float32)
+    qv = kl["y"] + rng.uniform(-1.5, 1.5, nq).astype(np.float32)
+    lvl = kl["octave"].astype(np.int32)
+    uright = np.where(rng.random(len(kr)) < 0.5, kr["x"] - 5.0, -1.0).astype(np.float32)
+    qur = (qu - 5.0).astype(np.float32)
+    claimed0 = np.full(len(kr), -1, np.int32); claimed0[::13] = 0
+    for th, ratio in ((1.0, 0.8), (3.0, 0.8), (5.0, 0.6)):
+        qr = (np.where(rng.random(nq) < 0.5, 2.5, 4.0) * th * scale[lvl]).astype(np.float32)
+        g = matcher.search_by_projection_mappoints(qu, qv, qr, qur, lvl, dl, kr, dr, uright, bounds, ratio, claimed0)
+        o = oracle.search_by_projection_mappoints(qu, qv, qr, qur, lvl, dl, kr, dr, uright, bounds, ratio, claimed0)
+        assert g[1] == o[1] and np.array_equal(g[0], o[0])
+    assert o[1] > 10
+    for mode in (0, 1, 2):
+        for th_dist, check_ori in ((100, True), (64, False)):
+            radius = (15.0 * scale[lvl]).astype(np.float32)
+            g = matcher.search_by_projection_lastframe(qu, qv, radius, qur, lvl, kl["angle"], dl, kr, dr, uright, bounds, mode, th_dist, check_ori, claimed0)
+            o = oracle.search_by_projection_lastframe(qu, qv, radius, qur, lvl, kl["angle"], dl, kr, dr, uright, bounds, mode, th_dist, check_ori, claimed0)
+            assert g[1] == o[1] and np.array_equal(g[0], o[0])
+    assert o[1] > 10
+
+
+def test_stereo_match(vsa, oracle, matcher, stereo_features):
+    w, h, kl, dl, kr, dr = stereo_features
+    scale = vsa.scale_tables(vsa.make_params())["scale"]
+    bf, fx = 47.90639384423901, 435.2046959714599       # EuRoC.yaml
+    mb = bf / fx
+    g = matcher.stereo_match(kl, dl, kr, dr, scale, h, 0.0, bf / mb)
+    o = oracle.stereo_match(kl, dl, kr, dr, scale, h, 0.0, bf / mb)
+    assert np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+    assert ((o[0] >= 0) & (o[0] < 75)).sum() > 50
+    g = matcher.stereo_match(kl, dl, kr[:0], dr[:0], scale, h, 0.0, bf / mb)
+    assert (g[0] == -1).all()
+
+
+def test_stereo_pipeline_device_resident(vsa, oracle, matcher):
+    """BASELINE config 2 shape: left+right extraction then stereo Hamming, all buffers in HBM."""
+    torch = pytest.importorskip("torch")
+    w, h, B = 752, 480, 2
+    p = vsa.make_params()
+    exl = vsa.Extractor(p, w, h, max_batch=B, device=0)
+    exr = vsa.Extractor(p, w, h, max_batch=B, device=0)
+    pairs = [vsa.synth_stereo(30 + i, w, h) for i in range(B)]
+    dev = torch.device("cuda:0")
+    L = torch.from_numpy(np.stack([p_[0] for p_ in pairs])).to(dev)
+    R = torch.from_numpy(np.stack([p_[1] for p_ in pairs])).to(dev)
+    cap = exl.cap
+    out = {}
+    for name, ex, imgs in (("l", exl, L), ("r", exr, R)):
+        k = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+        d = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        c = torch.zeros(B, dtype=torch.int32, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        ex.extract_batch_device(imgs.data_ptr(), w, w * h, B, k.data_ptr(), d.data_ptr(), c.data_ptr(), cap, s)
+        out[name] = (k, d, c)
+    bd = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    bi = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    scale = vsa.scale_tables(p)["scale"]
+    bf, fx = 47.90639384423901, 435.2046959714599
+    matcher.stereo_match_batch_device(out["l"][0].data_ptr(), out["l"][1].data_ptr(), out["l"][2].data_ptr(),
+                                      out["r"][0].data_ptr(), out["r"][1].data_ptr(), out["r"][2].data_ptr(),
+                                      cap, B, scale, h, 0.0, bf / (bf / fx), bd.data_ptr(), bi.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    oex = oracle.Extractor(oracle.make_params())
+    for i in range(B):
+        kl, dl = oex.extract(pairs[i][0]); kr, dr = oex.extract(pairs[i][1])
+        nl = int(out["l"][2][i])
+        assert nl == len(kl) and int(out["r"][2][i]) == len(kr)
+        assert np.array_equal(out["l"][1][i, :nl].cpu().numpy(), dl)
+        o = oracle.stereo_match(kl, dl, kr, dr, scale, h, 0.0, bf / (bf / fx))
+        assert np.array_equal(bd[i, :nl].cpu().numpy(), o[0]) and np.array_equal(bi[i, :nl].cpu().numpy(), o[1])
+    exl.close(); exr.close()

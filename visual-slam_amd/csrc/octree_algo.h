@@ -1,0 +1,334 @@
+// Level-synchronous formulation of DistributeOctTree (src/ORBextractor.cc:538-762).
+//
+// The reference walks a std::list, splitting nodes one at a time.  Each of its passes is a
+// data-parallel "split step" over a subset S of the list's nodes, processed in an order pi:
+//   coarse sweep (:605-664): S = every node with more than one key, pi = list order;
+//   fine pass   (:675-736): S = the largest nodes first (sorted by key count, ties by creation
+//                           sequence -- the reference's tie is the heap address, which no rerun
+//                           reproduces), cut as soon as the list holds N nodes.
+// After a step the list reads: children of the node processed LAST first (order n4,n3,n2,n1, empty
+// ones dropped) ... children of the node processed first, then every unsplit node in its old order.
+// Keys never move: each key carries the list position of its node, a node with one key keeps that
+// key in its record, and the best key of a larger node is found at the end by an atomic max.
+//
+// The same source builds for the device (one workgroup per (frame, level)) and, with
+// ORBX_OCTREE_HOST_SIM, as a single-thread host simulation used by the CPU unit tests.
+#pragma once
+#include <stdint.h>
+
+#ifdef ORBX_OCTREE_HOST_SIM
+#include <cmath>
+#define OT_DEV
+#define OT_TID 0
+#define OT_NT 1
+#define OT_SYNC() ((void)0)
+static inline int ot_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned ot_atomic_max(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+static inline float ot_fdiv(float a, float b) { return a / b; }
+#else
+#define OT_DEV __device__ __forceinline__
+#define OT_TID ((int)threadIdx.x)
+#define OT_NT ((int)blockDim.x)
+#define OT_SYNC() __syncthreads()
+static __device__ __forceinline__ int ot_atomic_add(int* p, int v) { return atomicAdd(p, v); }
+static __device__ __forceinline__ unsigned ot_atomic_max(unsigned* p, unsigned v) { return atomicMax(p, v); }
+static __device__ __forceinline__ float ot_fdiv(float a, float b) { return __fdiv_rn(a, b); }
+#endif
+
+namespace orbx {
+
+constexpr uint16_t kOtDead = 0xFFFF;
+
+struct OtNode {            // 16 bytes
+    int16_t x0, x1, y0, y1;
+    int32_t cnt;           // keys inside
+    uint32_t aux;          // cnt == 1: the packed key itself; cnt > 1: creation sequence number
+};
+
+// Shared (LDS) working set of one octree.  Capacities: nodes NC, keys live in global memory.
+struct OtShared {
+    OtNode* cur;           // [NC] current list, position = index
+    OtNode* nxt;           // [NC]
+    int32_t* cc;           // [NC*4] per candidate: child key counts, later child positions
+    int32_t* candPos;      // [NC] list position of candidate e
+    int32_t* pi;           // [NC] processing index of candidate e
+    int32_t* cByPi;        // [NC] non-empty child count by processing index -> exclusive scan
+    int32_t* keep;         // [NC] unsplit flag by position -> exclusive scan -> new position
+    int32_t* posToCand;    // [NC] candidate index of a position (or -1)
+    int32_t* scal;         // [16] scalars
+    int32_t* scanTmp;      // [NT/64 + 2] block-scan scratch (device)
+};
+enum { OT_N = 0, OT_E = 1, OT_C = 2, OT_RSTAR = 3, OT_NEXP = 4, OT_SEQ = 5, OT_TMP = 6, OT_NSPLIT = 7 };
+
+// exclusive prefix sum of a[0..n) in place; returns the total.  All threads call it.
+static OT_DEV int ot_block_scan(int32_t* a, int n, int32_t* tmp)
+{
+#ifdef ORBX_OCTREE_HOST_SIM
+    (void)tmp;
+    int run = 0;
+    for (int i = 0; i < n; ++i) { int v = a[i]; a[i] = run; run += v; }
+    return run;
+#else
+    const int tid = OT_TID, nt = OT_NT;
+    const int chunk = (n + nt - 1) / nt;
+    const int b = tid * chunk, e = min(b + chunk, n);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += a[i];
+    // inclusive scan of per-thread sums inside the wave
+    const int lane = tid & 63, wave = tid >> 6;
+    int inc = sum;
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    const int nw = (nt + 63) >> 6;
+    if (tid == 0) { int run = 0; for (int w = 0; w < nw; ++w) { int v = tmp[w]; tmp[w] = run; run += v; } tmp[nw] = run; }
+    __syncthreads();
+    int run = tmp[wave] + inc - sum;
+    for (int i = b; i < e; ++i) { int v = a[i]; a[i] = run; run += v; }
+    const int total = tmp[nw];
+    __syncthreads();
+    return total;
+#endif
+}
+
+static OT_DEV int ot_key_x(uint32_t k) { return (int)(k >> 20); }
+static OT_DEV int ot_key_y(uint32_t k) { return (int)((k >> 8) & 0xFFF); }
+
+// quadrant of a key inside node nd (DivideNode, :480-525): 0=n1 (top-left), 1=n2, 2=n3, 3=n4
+static OT_DEV int ot_quadrant(const OtNode& nd, uint32_t key)
+{
+    const int hx = (nd.x1 - nd.x0 + 1) >> 1;   // ceil((x1-x0)/2.f)
+    const int hy = (nd.y1 - nd.y0 + 1) >> 1;
+    const int right = ot_key_x(key) >= nd.x0 + hx;
+    const int bottom = ot_key_y(key) >= nd.y0 + hy;
+    return right + 2 * bottom;
+}
+
+static OT_DEV void ot_child_box(const OtNode& p, int q, OtNode& c)
+{
+    const int mx = p.x0 + ((p.x1 - p.x0 + 1) >> 1);
+    const int my = p.y0 + ((p.y1 - p.y0 + 1) >> 1);
+    c.x0 = (int16_t)((q & 1) ? mx : p.x0);
+    c.x1 = (int16_t)((q & 1) ? p.x1 : mx);
+    c.y0 = (int16_t)((q & 2) ? my : p.y0);
+    c.y1 = (int16_t)((q & 2) ? p.y1 : my);
+}
+
+// One split step.  fine == 0: coarse sweep; fine == 1: sorted pass with the cut at N.
+// keys / nodeOf: global arrays of nk entries.  Returns nothing; updates s.scal[OT_N], OT_NEXP, OT_SEQ
+// and swaps the roles of cur/nxt through the caller (the caller swaps pointers after the call).
+static OT_DEV void ot_split_step(OtShared& s, const uint32_t* keys, uint16_t* nodeOf, int nk, int N, int fine)
+{
+    const int tid = OT_TID, nt = OT_NT;
+    const int n = s.scal[OT_N];
+
+    // candidates = nodes with more than one key, in list order
+    for (int p = tid; p < n; p += nt) s.keep[p] = s.cur[p].cnt > 1 ? 1 : 0;
+    OT_SYNC();
+    const int E = ot_block_scan(s.keep, n, s.scanTmp);
+    for (int p = tid; p < n; p += nt) {
+        const int e = s.keep[p];
+        if (s.cur[p].cnt > 1) { s.candPos[e] = p; s.posToCand[p] = e; s.cc[4 * e] = 0; s.cc[4 * e + 1] = 0; s.cc[4 * e + 2] = 0; s.cc[4 * e + 3] = 0; }
+        else s.posToCand[p] = -1;
+    }
+    OT_SYNC();
+    // child key counts of every candidate
+    for (int k = tid; k < nk; k += nt) {
+        const uint16_t p = nodeOf[k];
+        if (p == kOtDead) continue;
+        const int e = s.posToCand[p];
+        ot_atomic_add(&s.cc[4 * e + ot_quadrant(s.cur[p], keys[k])], 1);
+    }
+    OT_SYNC();
+    // processing order
+    if (!fine) {
+        for (int e = tid; e < E; e += nt) s.pi[e] = e;
+        if (tid == 0) s.scal[OT_RSTAR] = E - 1;
+        OT_SYNC();
+    } else {
+        // rank by (count desc, sequence desc): the reference sorts ascending and walks from the back (:683-684)
+        for (int e = tid; e < E; e += nt) {
+            const OtNode& a = s.cur[s.candPos[e]];
+            int r = 0;
+            for (int m = 0; m < E; ++m) {
+                const OtNode& b = s.cur[s.candPos[m]];
+                r += (b.cnt > a.cnt) || (b.cnt == a.cnt && b.aux > a.aux);
+            }
+            s.pi[e] = r;
+        }
+        OT_SYNC();
+        // growth by rank, inclusive prefix, first rank at which the list reaches N (:729-730)
+        for (int e = tid; e < E; e += nt) {
+            const int* c = &s.cc[4 * e];
+            s.cByPi[s.pi[e]] = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) - 1;
+        }
+        if (tid == 0) s.scal[OT_RSTAR] = E - 1;
+        OT_SYNC();
+        ot_block_scan(s.cByPi, E, s.scanTmp);  // exclusive prefix of growth
+        for (int e = tid; e < E; e += nt) {
+            const int r = s.pi[e];
+            const int* c = &s.cc[4 * e];
+            const int g = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) - 1;
+            if (n + s.cByPi[r] + g >= N) {
+#ifdef ORBX_OCTREE_HOST_SIM
+                if (r < s.scal[OT_RSTAR]) s.scal[OT_RSTAR] = r;
+#else
+                atomicMin(&s.scal[OT_RSTAR], r);
+#endif
+            }
+        }
+        OT_SYNC();
+    }
+    const int rstar = s.scal[OT_RSTAR];
+    // non-empty child count by processing index (only the split ones), exclusive scan
+    for (int e = tid; e < E; e += nt) {
+        const int* c = &s.cc[4 * e];
+        if (s.pi[e] <= rstar) s.cByPi[s.pi[e]] = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
+    }
+    OT_SYNC();
+    const int nsplit = rstar + 1 < E ? rstar + 1 : E;
+    const int C = ot_block_scan(s.cByPi, nsplit, s.scanTmp);
+    // unsplit nodes keep their relative order behind the new children
+    for (int p = tid; p < n; p += nt) {
+        const int e = s.posToCand[p];
+        s.keep[p] = (e >= 0 && s.pi[e] <= rstar) ? 0 : 1;
+    }
+    OT_SYNC();
+    ot_block_scan(s.keep, n, s.scanTmp);
+    if (tid == 0) s.scal[OT_NEXP] = 0;
+    OT_SYNC();
+    const int seqBase = s.scal[OT_SEQ];
+    // write the new list
+    for (int p = tid; p < n; p += nt) {
+        const int e = s.posToCand[p];
+        if (e >= 0 && s.pi[e] <= rstar) {
+            int* c = &s.cc[4 * e];
+            const int cex = s.cByPi[s.pi[e]];
+            const int cn = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
+            const int bs = C - cex - cn;     // block of the node processed last comes first
+            int before = 0, nexp = 0;
+            for (int q = 0; q < 4; ++q) {
+                const int cnt = c[q];
+                if (cnt > 0) {
+                    const int after = cn - 1 - before;        // n4 sits at the front of the block
+                    const int np = bs + after;
+                    OtNode ch;
+                    ot_child_box(s.cur[p], q, ch);
+                    ch.cnt = cnt;
+                    ch.aux = (uint32_t)(seqBase + cex + before);
+                    s.nxt[np] = ch;
+                    c[q] = np;
+                    nexp += cnt > 1;
+                    ++before;
+                } else c[q] = -1;
+            }
+            if (nexp) ot_atomic_add(&s.scal[OT_NEXP], nexp);
+        } else {
+            const int np = C + s.keep[p];
+            s.nxt[np] = s.cur[p];
+            s.keep[p] = np;
+        }
+    }
+    OT_SYNC();
+    // keys follow their nodes
+    for (int k = tid; k < nk; k += nt) {
+        const uint16_t p = nodeOf[k];
+        if (p == kOtDead) continue;
+        const int e = s.posToCand[p];
+        if (s.pi[e] <= rstar) {
+            const uint32_t key = keys[k];
+            const int np = s.cc[4 * e + ot_quadrant(s.cur[p], key)];
+            if (s.nxt[np].cnt == 1) { s.nxt[np].aux = key; nodeOf[k] = kOtDead; }
+            else nodeOf[k] = (uint16_t)np;
+        } else nodeOf[k] = (uint16_t)s.keep[p];
+    }
+    OT_SYNC();
+    if (tid == 0) {
+        s.scal[OT_N] = C + (n - nsplit);
+        s.scal[OT_SEQ] = seqBase + C;
+        s.scal[OT_NSPLIT] = nsplit;
+    }
+    OT_SYNC();
+}
+
+// Whole DistributeOctTree for one key set.  keys: packed x<<20|y<<8|score (coordinates relative to
+// minBorder), nodeOf: scratch of nk uint16, W/H: maxX-minX / maxY-minY, nIni/hX: roots (:542-544).
+// out receives the selected keys in list order; returns their number (all threads).
+static OT_DEV int ot_distribute(OtShared& s, const uint32_t* keys, uint16_t* nodeOf, int nk,
+                                int W, int H, int nIni, float hX, int N, uint32_t* out, int outCap)
+{
+    const int tid = OT_TID, nt = OT_NT;
+    // roots (:551-569)
+    for (int i = tid; i < nIni; i += nt) {
+        OtNode r;
+        r.x0 = (int16_t)(int)(hX * (float)i);
+        r.x1 = (int16_t)(int)(hX * (float)(i + 1));
+        r.y0 = 0; r.y1 = (int16_t)H;
+        r.cnt = 0; r.aux = (uint32_t)i;
+        s.nxt[i] = r;
+    }
+    if (tid == 0) { s.scal[OT_SEQ] = nIni; }
+    OT_SYNC();
+    for (int k = tid; k < nk; k += nt) {
+        int r = (int)ot_fdiv((float)ot_key_x(keys[k]), hX);
+        if (r > nIni - 1) r = nIni - 1;
+        nodeOf[k] = (uint16_t)r;
+        ot_atomic_add(&s.nxt[r].cnt, 1);
+    }
+    OT_SYNC();
+    // drop empty roots (:571-584); a root with one key keeps it
+    for (int i = tid; i < nIni; i += nt) s.keep[i] = s.nxt[i].cnt > 0 ? 1 : 0;
+    OT_SYNC();
+    const int n0 = ot_block_scan(s.keep, nIni, s.scanTmp);
+    for (int i = tid; i < nIni; i += nt) if (s.nxt[i].cnt > 0) s.cur[s.keep[i]] = s.nxt[i];
+    OT_SYNC();
+    for (int k = tid; k < nk; k += nt) {
+        const int np = s.keep[nodeOf[k]];
+        if (s.cur[np].cnt == 1) { s.cur[np].aux = keys[k]; nodeOf[k] = kOtDead; }
+        else nodeOf[k] = (uint16_t)np;
+    }
+    if (tid == 0) s.scal[OT_N] = n0;
+    OT_SYNC();
+    (void)W;
+
+    // main loop (:593-738)
+    bool finish = false;
+    while (!finish) {
+        const int prevSize = s.scal[OT_N];
+        OT_SYNC();
+        ot_split_step(s, keys, nodeOf, nk, N, 0);
+        { OtNode* t = s.cur; s.cur = s.nxt; s.nxt = t; }
+        const int n = s.scal[OT_N], nToExpand = s.scal[OT_NEXP];
+        if (n >= N || n == prevSize) finish = true;
+        else if (n + nToExpand * 3 > N) {
+            while (!finish) {
+                const int prev2 = s.scal[OT_N];
+                OT_SYNC();
+                ot_split_step(s, keys, nodeOf, nk, N, 1);
+                { OtNode* t = s.cur; s.cur = s.nxt; s.nxt = t; }
+                const int n2 = s.scal[OT_N];
+                if (n2 >= N || n2 == prev2) finish = true;
+            }
+        }
+    }
+    OT_SYNC();
+    // best key per node (:741-759): largest response, first in input order on ties
+    const int n = s.scal[OT_N];
+    unsigned* best = reinterpret_cast<unsigned*>(s.keep);
+    for (int p = tid; p < n; p += nt) best[p] = 0;
+    OT_SYNC();
+    for (int k = tid; k < nk; k += nt) {
+        const uint16_t p = nodeOf[k];
+        if (p == kOtDead) continue;
+        ot_atomic_max(&best[p], ((keys[k] & 0xFFu) << 24) | (0xFFFFFFu - (unsigned)k));
+    }
+    OT_SYNC();
+    for (int p = tid; p < n && p < outCap; p += nt) {
+        const OtNode& nd = s.cur[p];
+        out[p] = nd.cnt == 1 ? nd.aux : keys[0xFFFFFFu - (best[p] & 0xFFFFFFu)];
+    }
+    OT_SYNC();
+    return n;
+}
+
+} // namespace orbx

@@ -1,0 +1,858 @@
+// MI355X (gfx950) kernels and context of the ORB extractor: ORBextractor::operator()
+// (src/ORBextractor.cc:1042-1104) for a batch of equally sized frames resident in HBM.
+//
+// Launch sequence per batch (all on one stream, grids over (tile, frame)):
+//   k_level0      copy + REFLECT_101 border                      ComputePyramid :1124-1128
+//   k_resize x(L-1)  fixed-point bilinear + border, level l from l-1  ComputePyramid :1117-1123
+//   k_fast_cells  per-cell FAST-9 score, NMS, threshold fallback   ComputeKeyPointsOctTree :788-828
+//   k_octree      quadtree selection, one workgroup per level      DistributeOctTree :538-762
+//   k_describe    IC angle, 7x7 Gaussian on the patch, rBRIEF, output record  :76-146, :1084-1102
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "orbx_internal.h"
+#include "octree_algo.h"
+
+using namespace orbx;
+
+#define HIP_CHECK(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+            return ORBX_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+// Per-level constants as the kernels see them.
+struct DevLevel {
+    int w, h, stride, rows;
+    unsigned long long offset, roi;
+    int maxBorderX, maxBorderY;
+    int cell_first, cell_count, cand_offset, cand_cap;
+    int quota, nIni;
+    float hX;
+    int kp_offset, kp_cap;
+    int area2x, rx_offset, ry_offset;
+    float scale, kp_size;
+    int key_offset;   // offset of this level's compact key array inside one frame's key scratch
+    int pad;
+};
+
+__device__ __constant__ signed char c_pattern[1024] = {
+#include "../../include/orbx_pattern.inc"
+};
+// circular patch row ends (src/ORBextractor.cc:453-468); constant for HALF_PATCH_SIZE = 15
+__device__ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return *reinterpret_cast<const u32_unaligned*>(p); }
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    // one reflection is enough for |overshoot| <= 19 < len
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * len - 2 - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level 0: copy the input into the padded pyramid buffer and write the REFLECT_101 frame.
+// One thread writes one aligned dword of a padded row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img, long long row_stride, long long frame_stride,
+                                                uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L)
+{
+    const int c = 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (c >= L.stride) return;
+    const int py = blockIdx.y - kEdge;
+    const int sy = reflect101(py, L.h);
+    const uint8_t* srow = img + (long long)blockIdx.z * frame_stride + (long long)sy * row_stride;
+    uint8_t* drow = pyr + (unsigned long long)blockIdx.z * pyr_bytes + L.offset + (unsigned long long)blockIdx.y * L.stride;
+    const int x = c - kRoiX;
+    uint32_t v;
+    if (x >= 0 && x + 3 < L.w) {
+        v = load_u32(srow + x);
+    } else {
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = x + k;
+            uint32_t b = 0;
+            if (xx >= -kEdge && xx < L.w + kEdge) b = srow[reflect101(xx, L.w)];
+            v |= b << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(drow + c) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level l from level l-1: cv::resize INTER_LINEAR for 8-bit (Q11 weights, two-stage rounding) and
+// the REFLECT_101 frame in the same pass (a frame pixel is the interior pixel it mirrors).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel S, DevLevel D,
+                                                const ResizeX* __restrict__ rxt, const ResizeY* __restrict__ ryt)
+{
+    const int c = 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (c >= D.stride) return;
+    uint8_t* base = pyr + (unsigned long long)blockIdx.z * pyr_bytes;
+    const uint8_t* sroi = base + S.roi;
+    const int y = reflect101((int)blockIdx.y - kEdge, D.h);
+    const ResizeY ey = ryt[D.ry_offset + y];
+    const uint8_t* s0 = sroi + (long long)ey.sy0 * S.stride;
+    const uint8_t* s1 = sroi + (long long)ey.sy1 * S.stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xx = c + k - kRoiX;
+        uint32_t b = 0;
+        if (xx >= -kEdge && xx < D.w + kEdge) {
+            const ResizeX ex = rxt[D.rx_offset + reflect101(xx, D.w)];
+            const int p00 = s0[ex.sx], p01 = s0[ex.sx + 1], p10 = s1[ex.sx], p11 = s1[ex.sx + 1];
+            if (D.area2x) {
+                b = (uint32_t)((p00 + p01 + p10 + p11 + 2) >> 2);
+            } else {
+                const int h0 = p00 * ex.a0 + p01 * ex.a1;
+                const int h1 = p10 * ex.a0 + p11 * ex.a1;
+                b = (uint32_t)((((ey.b0 * (h0 >> 4)) >> 16) + ((ey.b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;
+            }
+        }
+        v |= b << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(base + D.offset + (unsigned long long)blockIdx.y * D.stride + c) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST-9 per cell (cv::FAST(cell, kps, T, true) with T = iniThFAST, else minThFAST).
+//
+// corner at threshold T  <=>  s >= T with  s = max over the 16 arcs of 9 contiguous ring pixels of
+// min(one-signed difference) - 1, which is also the score OpenCV stores.  Non-maximum suppression
+// compares the 8 neighbours inside the cell's own detection area only (outside counts as 0), so
+// the set of local maxima does not depend on T; T only filters it.  A cell therefore needs one
+// score pass: keep maxima with s >= ini if there is one, otherwise those with s >= min.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileStride = 72;   // bytes per LDS tile row (cells are at most 59 wide: 59+6 <= 68)
+constexpr int kTileRows = 68;
+constexpr int kScoreStride = 64;
+constexpr int kMaxCellDim = 60;
+
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+// exact score of the pixel at tile address t (ring offsets in tile coordinates)
+__device__ __forceinline__ int fast_score(const uint8_t* t)
+{
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * kTileStride];
+    d[1] = v - t[3 * kTileStride + 1];
+    d[2] = v - t[2 * kTileStride + 2];
+    d[3] = v - t[kTileStride + 3];
+    d[4] = v - t[3];
+    d[5] = v - t[-kTileStride + 3];
+    d[6] = v - t[-2 * kTileStride + 2];
+    d[7] = v - t[-3 * kTileStride + 1];
+    d[8] = v - t[-3 * kTileStride];
+    d[9] = v - t[-3 * kTileStride - 1];
+    d[10] = v - t[-2 * kTileStride - 2];
+    d[11] = v - t[-kTileStride - 3];
+    d[12] = v - t[-3];
+    d[13] = v - t[kTileStride - 3];
+    d[14] = v - t[2 * kTileStride - 2];
+    d[15] = v - t[3 * kTileStride - 1];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    }
+    int dark = -256, bright = 256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        dark = max(dark, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));     // min over ring k..k+8
+        bright = min(bright, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15])); // max over ring k..k+8
+    }
+    return max(dark, -bright) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
+                                                    const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
+                                                    uint32_t* __restrict__ cand, int cand_total,
+                                                    uint16_t* __restrict__ cellcnt, int ncells, int iniTh, int minTh)
+{
+    __shared__ __align__(16) uint8_t tile[kTileRows * kTileStride];
+    __shared__ __align__(16) uint8_t score[(kMaxCellDim + 2) * kScoreStride];
+    __shared__ uint16_t queue[kMaxCellDim * kMaxCellDim];
+    __shared__ int qn;
+    __shared__ int wcount[4];
+    __shared__ int anyIni;
+    __shared__ int outBase;
+
+    const int tid = threadIdx.x;
+    const CellRec c = cells[blockIdx.x];
+    const DevLevel& L = lv[c.level];
+    const uint8_t* src = pyr + (unsigned long long)blockIdx.y * pyr_bytes + L.roi + (long long)c.y0 * L.stride + c.x0;
+    const int cw = c.cw, ch = c.ch;
+    const int tw = cw + 6, th = ch + 6;
+    const int dpr = (tw + 3) >> 2; // dwords per tile row
+    for (int i = tid; i < th * dpr; i += 256) {
+        const int r = i / dpr, d = i - r * dpr;
+        *reinterpret_cast<uint32_t*>(&tile[r * kTileStride + 4 * d]) = load_u32(src + (long long)r * L.stride + 4 * d);
+    }
+    for (int i = tid; i < (ch + 2) * (kScoreStride / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
+    if (tid == 0) { qn = 0; anyIni = 0; outBase = 0; }
+    __syncthreads();
+
+    const int lowTh = min(iniTh, minTh);
+    const int npix = cw * ch;
+    // pass 1: a 9-arc always holds two adjacent compass points (0,4,8,12): cheap necessary test
+    for (int i = tid; i < npix; i += 256) {
+        const int y = i / cw, x = i - y * cw;
+        const uint8_t* t = &tile[(y + 3) * kTileStride + x + 3];
+        const int v = t[0];
+        const int d0 = v - t[3 * kTileStride], d4 = v - t[3], d8 = v - t[-3 * kTileStride], d12 = v - t[-3];
+        const int dk = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
+        const int br = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
+        if (dk > lowTh || br < -lowTh) {
+            const int slot = atomicAdd(&qn, 1);
+            queue[slot] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    // pass 2: exact score of the survivors
+    const int nq = qn;
+    for (int e = tid; e < nq; e += 256) {
+        const int i = queue[e];
+        const int y = i / cw, x = i - y * cw;
+        const int s = fast_score(&tile[(y + 3) * kTileStride + x + 3]);
+        if (s >= lowTh && s >= 1) score[(y + 1) * kScoreStride + x + 1] = (uint8_t)s;
+    }
+    __syncthreads();
+    // pass 3: strict local maxima inside the cell; does any reach the initial threshold?
+    const int iters = (npix + 255) >> 8;
+    uint32_t keptMask = 0;
+    bool ini = false;
+    for (int it = 0; it < iters; ++it) {
+        const int i = it * 256 + tid;
+        if (i < npix) {
+            const int y = i / cw, x = i - y * cw;
+            const uint8_t* sp = &score[(y + 1) * kScoreStride + x + 1];
+            const int s = sp[0];
+            if (s > 0) {
+                const bool mx = s > sp[-1] && s > sp[1] &&
+                                s > sp[-kScoreStride - 1] && s > sp[-kScoreStride] && s > sp[-kScoreStride + 1] &&
+                                s > sp[kScoreStride - 1] && s > sp[kScoreStride] && s > sp[kScoreStride + 1];
+                if (mx) { keptMask |= 1u << it; ini |= (s >= iniTh); }
+            }
+        }
+    }
+    if (__any(ini) && (tid & 63) == 0) anyIni = 1;
+    __syncthreads();
+    const int T = max(anyIni ? iniTh : minTh, 1);
+    // pass 4: ordered (raster) compaction into this cell's slots
+    uint32_t* out = cand + (unsigned long long)blockIdx.y * cand_total + L.cand_offset + c.slot;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int it = 0; it < iters; ++it) {
+        const int i = it * 256 + tid;
+        bool emit = false;
+        int x = 0, y = 0, s = 0;
+        if ((keptMask >> it) & 1u) {
+            y = i / cw; x = i - y * cw;
+            s = score[(y + 1) * kScoreStride + x + 1];
+            emit = s >= T;
+        }
+        const unsigned long long m = __ballot(emit);
+        if (lane == 0) wcount[wave] = __popcll(m);
+        __syncthreads();
+        int base = outBase;
+        for (int w = 0; w < wave; ++w) base += wcount[w];
+        if (emit) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < c.cap)
+                out[pos] = ((uint32_t)(x + 3 + c.offx) << 20) | ((uint32_t)(y + 3 + c.offy) << 8) | (uint32_t)s;
+        }
+        __syncthreads();
+        if (tid == 0) outBase += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (tid == 0) cellcnt[(unsigned long long)blockIdx.y * ncells + blockIdx.x] = (uint16_t)min(outBase, c.cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quadtree selection: one workgroup per (level, frame).  Gathers the per-cell candidate slots into a
+// dense key array (cell-row-major, raster inside a cell: the reference's vToDistributeKeys order),
+// then runs the level-synchronous DistributeOctTree of octree_algo.h.
+// ---------------------------------------------------------------------------------------------
+constexpr int kOctThreads = 1024;
+
+__device__ void ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads)
+{
+    size_t o = 0;
+    s.cur = reinterpret_cast<OtNode*>(mem + o); o += sizeof(OtNode) * NC;
+    s.nxt = reinterpret_cast<OtNode*>(mem + o); o += sizeof(OtNode) * NC;
+    s.cc = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * 4 * NC;
+    s.candPos = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * NC;
+    s.pi = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * NC;
+    s.cByPi = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * NC;
+    s.keep = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * NC;
+    s.posToCand = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * NC;
+    s.scal = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * 16;
+    s.scanTmp = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * (nthreads / 64 + 2);
+}
+size_t ot_lds_bytes(int NC, int nthreads)
+{
+    return sizeof(OtNode) * 2 * NC + sizeof(int32_t) * (4 + 5) * NC + sizeof(int32_t) * 16 + sizeof(int32_t) * (nthreads / 64 + 2);
+}
+
+__global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
+                                                        const uint32_t* __restrict__ cand, int cand_total,
+                                                        const uint16_t* __restrict__ cellcnt, int ncells,
+                                                        uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int key_total,
+                                                        uint32_t* __restrict__ lvlkp, int kp_total,
+                                                        int32_t* __restrict__ lvlcnt, int nlevels, int NCmax)
+{
+    extern __shared__ __align__(16) unsigned char ot_mem[];
+    __shared__ int s_nk;
+    const int tid = threadIdx.x;
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const DevLevel& L = lv[level];
+    OtShared s;
+    ot_carve(s, ot_mem, NCmax, kOctThreads);
+
+    // gather: exclusive scan of the cell counts in chunks, then copy each cell's slots
+    uint32_t* K = keys + (unsigned long long)frame * key_total + L.key_offset;
+    uint16_t* NO = nodeOf + (unsigned long long)frame * key_total + L.key_offset;
+    const uint16_t* cnt = cellcnt + (unsigned long long)frame * ncells + L.cell_first;
+    const uint32_t* slots = cand + (unsigned long long)frame * cand_total + L.cand_offset;
+    if (tid == 0) s_nk = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < L.cell_count; c0 += NCmax) {
+        const int m = min(NCmax, L.cell_count - c0);
+        for (int i = tid; i < m; i += kOctThreads) s.keep[i] = cnt[c0 + i];
+        __syncthreads();
+        const int tot = ot_block_scan(s.keep, m, s.scanTmp);
+        const int base = s_nk;
+        for (int i = tid; i < m; i += kOctThreads) {
+            const CellRec& cr = cells[L.cell_first + c0 + i];
+            const int n = cnt[c0 + i];
+            const int o = base + s.keep[i];
+            for (int j = 0; j < n; ++j) K[o + j] = slots[cr.slot + j];
+        }
+        __syncthreads();
+        if (tid == 0) s_nk = base + tot;
+        __syncthreads();
+    }
+    const int nk = s_nk;
+    __threadfence_block();
+    __syncthreads();
+    uint32_t* out = lvlkp + (unsigned long long)frame * kp_total + L.kp_offset;
+    const int n = ot_distribute(s, K, NO, nk, L.maxBorderX - kMinBorder, L.maxBorderY - kMinBorder, L.nIni, L.hX, L.quota, out, L.kp_cap);
+    if (tid == 0) lvlcnt[frame * nlevels + level] = min(n, L.kp_cap);
+}
+
+// standalone form for parity tests: keys already dense
+__global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int nk,
+                                                               int W, int H, int nIni, float hX, int N,
+                                                               uint32_t* __restrict__ out, int outCap, int32_t* __restrict__ nOut, int NC)
+{
+    extern __shared__ __align__(16) unsigned char ot_mem[];
+    OtShared s;
+    ot_carve(s, ot_mem, NC, kOctThreads);
+    const int n = ot_distribute(s, keys, nodeOf, nk, W, H, nIni, hX, N, out, outCap);
+    if (threadIdx.x == 0) *nOut = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Describe: one wavefront per selected keypoint.  The 43x43 neighbourhood is staged in LDS once and
+// serves the intensity centroid (radius 15, unblurred), the separable 7x7 Gaussian restricted to the
+// 37x37 window the rotated pattern can reach, and the 256 binary tests.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPatchW = 43, kPatchStride = 44, kBlurW = 37, kHStride = 38, kBlurStride = 40;
+
+// LDS hand-off between the lanes of one wavefront: DS operations of a wave execute in issue order,
+// so only the compiler has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    // cv::fastAtan2 scalar path; every operation rounded (no contraction)
+    constexpr float rad2deg = (float)(180.0 / 3.1415926535897932384626433832795);
+    constexpr float p1 = 0.9997878412794807f * rad2deg, p3 = -0.3258083974640975f * rad2deg;
+    constexpr float p5 = 0.1555786518463281f * rad2deg, p7 = -0.04432655554792128f * rad2deg;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    const float eps = 2.22044605e-16f; // (float)DBL_EPSILON
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
+                                                  const DevLevel* __restrict__ lv, int nlevels,
+                                                  const uint32_t* __restrict__ lvlkp, int kp_total,
+                                                  const int32_t* __restrict__ lvlcnt,
+                                                  orbx_keypoint* __restrict__ okp, uint8_t* __restrict__ odesc,
+                                                  int32_t* __restrict__ ocount, int cap_per_frame, int blur_rounding)
+{
+    __shared__ __align__(16) uint8_t s_patch[4][kPatchW * kPatchStride];
+    __shared__ __align__(16) uint16_t s_h[4][kPatchW * kHStride];
+    __shared__ __align__(16) uint8_t s_blur[4][kBlurW * kBlurStride];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.y;
+    const int slot = blockIdx.x * 4 + wave;
+    // locate (level, index) of this slot and the output offset of the level
+    int level = -1, idx = 0, outOff = 0, total = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const int cnt = lvlcnt[frame * nlevels + l];
+        const int o = lv[l].kp_offset;
+        if (slot >= o && slot < o + lv[l].kp_cap) { level = l; idx = slot - o; outOff = total; }
+        total += cnt;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ocount[frame] = total;
+    if (level < 0) return;
+    if (idx >= lvlcnt[frame * nlevels + level]) return;
+    if (outOff + idx >= cap_per_frame) return;
+    const DevLevel& L = lv[level];
+    const uint32_t key = lvlkp[(unsigned long long)frame * kp_total + L.kp_offset + idx];
+    const int kx = (int)(key >> 20) + kMinBorder, ky = (int)((key >> 8) & 0xFFF) + kMinBorder;
+    const int resp = (int)(key & 0xFF);
+
+    uint8_t* patch = s_patch[wave];
+    uint16_t* hbuf = s_h[wave];
+    uint8_t* blur = s_blur[wave];
+    const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + L.roi + (long long)(ky - 21) * L.stride + (kx - 21);
+    for (int i = lane; i < kPatchW * 11; i += 64) {
+        const int r = i / 11, d = i - r * 11;
+        *reinterpret_cast<uint32_t*>(&patch[r * kPatchStride + 4 * d]) = load_u32(src + (long long)r * L.stride + 4 * d);
+    }
+    wave_sync();
+
+    // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc
+    int m10 = 0, m01 = 0;
+    {
+        const int u = lane - kHalfPatch;
+        if (lane <= 2 * kHalfPatch) {
+            for (int v = -kHalfPatch; v <= kHalfPatch; ++v) {
+                const int av = v < 0 ? -v : v;
+                if (u >= -c_umax[av] && u <= c_umax[av]) {
+                    const int I = patch[(21 + v) * kPatchStride + 21 + u];
+                    m10 += u * I;
+                    m01 += v * I;
+                }
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // GaussianBlur 7x7 sigma 2 (src/ORBextractor.cc:1085): Q8 taps 18,34,49,55,49,34,18
+    // rows of the window: patch rows 0..42 -> horizontal sums for columns 3..39 (window column j <-> patch column j+3)
+    for (int i = lane; i < kPatchW * kBlurW; i += 64) {
+        const int r = i / kBlurW, j = i - r * kBlurW;
+        const uint8_t* p = &patch[r * kPatchStride + j];
+        const int sum = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+        hbuf[r * kHStride + j] = (uint16_t)sum;
+    }
+    wave_sync();
+    const int simdW = blur_rounding ? (L.w & ~3) : 0;
+    for (int i = lane; i < kBlurW * kBlurW; i += 64) {
+        const int r = i / kBlurW, j = i - r * kBlurW;
+        const uint16_t* p = &hbuf[r * kHStride + j];
+        const int sum = 18 * ((int)p[0] + p[6 * kHStride]) + 34 * ((int)p[kHStride] + p[5 * kHStride]) +
+                        49 * ((int)p[2 * kHStride] + p[4 * kHStride]) + 55 * (int)p[3 * kHStride];
+        const int imgx = kx - 18 + j;
+        int v = (imgx < simdW) ? ((sum + 32767 + ((sum >> 16) & 1)) >> 16) : ((sum + 32768) >> 16);
+        blur[r * kBlurStride + j] = (uint8_t)min(v, 255);
+    }
+    wave_sync();
+
+    // computeOrbDescriptor (src/ORBextractor.cc:107-146)
+    constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.0); // (float)(CV_PI/180.f)
+    const float ang = __fmul_rn(angle, factorPI);
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    const size_t orow = (size_t)frame * cap_per_frame + outOff + idx;
+    unsigned long long* dout = reinterpret_cast<unsigned long long*>(odesc + orow * 32);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int t = g * 64 + lane;
+        const float x0 = (float)c_pattern[4 * t], y0 = (float)c_pattern[4 * t + 1];
+        const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
+        const int r0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = blur[(18 + r0) * kBlurStride + 18 + c0];
+        const int t1 = blur[(18 + r1) * kBlurStride + 18 + c1];
+        const unsigned long long bits = __ballot(t0 < t1);
+        if (lane == 0) dout[g] = bits;
+    }
+    if (lane == 0) {
+        orbx_keypoint kp;
+        kp.x = (float)kx; kp.y = (float)ky;
+        if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }
+        kp.size = L.kp_size;
+        kp.angle = angle;
+        kp.response = (float)resp;
+        kp.octave = level;
+        kp.class_id = -1;
+        okp[orow] = kp;
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Context
+// ---------------------------------------------------------------------------------------------
+struct orbx_extractor {
+    orbx_params params;
+    Geometry geo;
+    int device = 0;
+    int max_batch = 0;
+    hipStream_t stream = nullptr;
+    std::vector<DevLevel> hlv;
+    DevLevel* d_lv = nullptr;
+    CellRec* d_cells = nullptr;
+    ResizeX* d_rx = nullptr;
+    ResizeY* d_ry = nullptr;
+    uint8_t* d_pyr = nullptr;
+    uint32_t* d_cand = nullptr;
+    uint16_t* d_cellcnt = nullptr;
+    uint32_t* d_keys = nullptr;
+    uint16_t* d_nodeof = nullptr;
+    uint32_t* d_lvlkp = nullptr;
+    int32_t* d_lvlcnt = nullptr;
+    // staging for the host entry points
+    uint8_t* d_img = nullptr;
+    orbx_keypoint* d_okp = nullptr;
+    uint8_t* d_odesc = nullptr;
+    int32_t* d_ocount = nullptr;
+    int key_total = 0;
+    int NCmax = 0;
+    size_t oct_lds = 0;
+    int last_frames = 0;
+    bool profiling = false;
+    hipEvent_t ev[ORBX_STAGE_COUNT + 1] = {};
+    float stage_ms[ORBX_STAGE_COUNT] = {};
+};
+
+static int select_device(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return ORBX_ERR_NO_DEVICE; }
+    if (device >= count) { set_error("device index out of range"); return ORBX_ERR_BAD_ARG; }
+    if (device >= 0) HIP_CHECK(hipSetDevice(device));
+    return ORBX_OK;
+}
+
+extern "C" {
+
+int orbx_extractor_create(const orbx_params* p, int width, int height, int max_batch, int device, orbx_extractor** out)
+{
+    if (!p || !out || max_batch < 1) { set_error("orbx_extractor_create: bad argument"); return ORBX_ERR_BAD_ARG; }
+    *out = nullptr;
+    Geometry geo;
+    int rc = build_geometry(*p, width, height, geo);
+    if (rc) return rc;
+    if (geo.max_cell_dim > kMaxCellDim) { set_error("cell larger than 60 pixels"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+    rc = select_device(device);
+    if (rc) return rc;
+    orbx_extractor* ex = new orbx_extractor();
+    ex->params = *p; ex->geo = geo; ex->max_batch = max_batch;
+    HIP_CHECK(hipGetDevice(&ex->device));
+    ex->hlv.resize(geo.nlevels);
+    int key_off = 0, ncmax = 0;
+    for (int l = 0; l < geo.nlevels; ++l) {
+        const LevelGeom& g = geo.lv[l];
+        DevLevel d{};
+        d.w = g.w; d.h = g.h; d.stride = g.stride; d.rows = g.rows; d.offset = g.offset; d.roi = g.roi;
+        d.maxBorderX = g.maxBorderX; d.maxBorderY = g.maxBorderY;
+        d.cell_first = g.cell_first; d.cell_count = g.cell_count; d.cand_offset = g.cand_offset; d.cand_cap = g.cand_cap;
+        d.quota = g.quota; d.nIni = g.nIni; d.hX = g.hX; d.kp_offset = g.kp_offset; d.kp_cap = g.kp_cap;
+        d.area2x = g.area2x; d.rx_offset = g.rx_offset; d.ry_offset = g.ry_offset; d.scale = g.scale; d.kp_size = g.kp_size;
+        d.key_offset = key_off;
+        key_off += (g.cand_cap + 3) & ~3;
+        ncmax = std::max(ncmax, g.kp_cap);
+        ex->hlv[l] = d;
+    }
+    ex->key_total = key_off;
+    ex->NCmax = std::max(ncmax + 8, 64);
+    ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads);
+    if (ex->oct_lds > 150 * 1024) { delete ex; set_error("per-level keypoint quota too large for the quadtree working set in LDS"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ex->oct_lds));
+    HIP_CHECK(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
+    const size_t B = (size_t)max_batch;
+    HIP_CHECK(hipMalloc(&ex->d_lv, sizeof(DevLevel) * geo.nlevels));
+    HIP_CHECK(hipMalloc(&ex->d_cells, sizeof(CellRec) * std::max<size_t>(geo.cells.size(), 1)));
+    HIP_CHECK(hipMalloc(&ex->d_rx, sizeof(ResizeX) * std::max<size_t>(geo.rx.size(), 1)));
+    HIP_CHECK(hipMalloc(&ex->d_ry, sizeof(ResizeY) * std::max<size_t>(geo.ry.size(), 1)));
+    HIP_CHECK(hipMemcpy(ex->d_lv, ex->hlv.data(), sizeof(DevLevel) * geo.nlevels, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(ex->d_cells, geo.cells.data(), sizeof(CellRec) * geo.cells.size(), hipMemcpyHostToDevice));
+    if (!geo.rx.empty()) HIP_CHECK(hipMemcpy(ex->d_rx, geo.rx.data(), sizeof(ResizeX) * geo.rx.size(), hipMemcpyHostToDevice));
+    if (!geo.ry.empty()) HIP_CHECK(hipMemcpy(ex->d_ry, geo.ry.data(), sizeof(ResizeY) * geo.ry.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&ex->d_pyr, geo.pyr_bytes * B + 256));
+    HIP_CHECK(hipMemset(ex->d_pyr, 0, geo.pyr_bytes * B + 256));
+    HIP_CHECK(hipMalloc(&ex->d_cand, sizeof(uint32_t) * (size_t)geo.cand_total * B));
+    HIP_CHECK(hipMalloc(&ex->d_cellcnt, sizeof(uint16_t) * geo.cells.size() * B));
+    HIP_CHECK(hipMalloc(&ex->d_keys, sizeof(uint32_t) * (size_t)ex->key_total * B));
+    HIP_CHECK(hipMalloc(&ex->d_nodeof, sizeof(uint16_t) * (size_t)ex->key_total * B));
+    HIP_CHECK(hipMalloc(&ex->d_lvlkp, sizeof(uint32_t) * (size_t)geo.kp_total * B));
+    HIP_CHECK(hipMalloc(&ex->d_lvlcnt, sizeof(int32_t) * geo.nlevels * B));
+    for (auto& e : ex->ev) HIP_CHECK(hipEventCreate(&e));
+    *out = ex;
+    return ORBX_OK;
+}
+
+void orbx_extractor_destroy(orbx_extractor* ex)
+{
+    if (!ex) return;
+    (void)hipSetDevice(ex->device);
+    if (ex->stream) (void)hipStreamSynchronize(ex->stream);
+    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_rx, ex->d_ry, ex->d_pyr, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
+                    ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : ex->ev) if (e) (void)hipEventDestroy(e);
+    if (ex->stream) (void)hipStreamDestroy(ex->stream);
+    delete ex;
+}
+
+int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                              int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap_per_frame,
+                              void* stream)
+{
+    if (!ex || !d_images || !d_kps || !d_desc || !d_counts) { set_error("orbx_extract_batch_device: null pointer"); return ORBX_ERR_BAD_ARG; }
+    if (n_frames < 1 || n_frames > ex->max_batch) { set_error("n_frames outside [1, max_batch]"); return ORBX_ERR_BAD_ARG; }
+    if (row_stride < ex->geo.width || cap_per_frame < 1) { set_error("row_stride < width or cap_per_frame < 1"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(ex->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ex->stream;
+    const Geometry& G = ex->geo;
+    const int B = n_frames;
+    const bool prof = ex->profiling;
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[0], st));
+    {
+        const DevLevel& L0 = ex->hlv[0];
+        dim3 grid((L0.stride / 4 + 255) / 256, L0.rows, B);
+        hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
+                           ex->d_pyr, (unsigned long long)G.pyr_bytes, L0);
+        for (int l = 1; l < G.nlevels; ++l) {
+            const DevLevel& D = ex->hlv[l];
+            dim3 g2((D.stride / 4 + 255) / 256, D.rows, B);
+            hipLaunchKernelGGL(k_resize, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
+                               ex->d_rx, ex->d_ry);
+        }
+    }
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
+    {
+        dim3 grid((unsigned)G.cells.size(), B);
+        hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells,
+                           ex->d_cand, G.cand_total, ex->d_cellcnt, (int)G.cells.size(), ex->params.ini_th_fast,
+                           ex->params.min_th_fast);
+    }
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
+    {
+        dim3 grid(G.nlevels, B);
+        hipLaunchKernelGGL(k_octree, grid, dim3(kOctThreads), ex->oct_lds, st, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total,
+                           ex->d_cellcnt, (int)G.cells.size(), ex->d_keys, ex->d_nodeof, ex->key_total, ex->d_lvlkp,
+                           G.kp_total, ex->d_lvlcnt, G.nlevels, ex->NCmax);
+    }
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
+    {
+        dim3 grid((G.kp_total + 3) / 4, B);
+        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels,
+                           ex->d_lvlkp, G.kp_total, ex->d_lvlcnt, d_kps, d_desc, d_counts, cap_per_frame,
+                           ex->params.blur_rounding);
+    }
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
+    HIP_CHECK(hipGetLastError());
+    ex->last_frames = B;
+    return ORBX_OK;
+}
+
+static int ensure_staging(orbx_extractor* ex)
+{
+    if (ex->d_img) return ORBX_OK;
+    const size_t B = (size_t)ex->max_batch;
+    const Geometry& G = ex->geo;
+    HIP_CHECK(hipMalloc(&ex->d_img, (size_t)G.width * G.height * B + 16));
+    HIP_CHECK(hipMalloc(&ex->d_okp, sizeof(orbx_keypoint) * (size_t)G.out_cap * B));
+    HIP_CHECK(hipMalloc(&ex->d_odesc, (size_t)32 * G.out_cap * B));
+    HIP_CHECK(hipMalloc(&ex->d_ocount, sizeof(int32_t) * B));
+    return ORBX_OK;
+}
+
+int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_stride, ptrdiff_t frame_stride, int n_frames,
+                       orbx_keypoint* kps, uint8_t* desc, int32_t* counts, int cap_per_frame)
+{
+    if (!ex || !images || !kps || !desc || !counts) { set_error("orbx_extract_batch: null pointer"); return ORBX_ERR_BAD_ARG; }
+    if (n_frames < 1 || n_frames > ex->max_batch) { set_error("n_frames outside [1, max_batch]"); return ORBX_ERR_BAD_ARG; }
+    if (row_stride < ex->geo.width) { set_error("row_stride < width"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(ex->device));
+    int rc = ensure_staging(ex);
+    if (rc) return rc;
+    const Geometry& G = ex->geo;
+    const size_t fbytes = (size_t)G.width * G.height;
+    for (int f = 0; f < n_frames; ++f)
+        HIP_CHECK(hipMemcpy2DAsync(ex->d_img + f * fbytes, G.width, images + (ptrdiff_t)f * frame_stride, row_stride, G.width, G.height,
+                                   hipMemcpyHostToDevice, ex->stream));
+    rc = orbx_extract_batch_device(ex, ex->d_img, G.width, (ptrdiff_t)fbytes, n_frames, ex->d_okp, ex->d_odesc, ex->d_ocount, G.out_cap,
+                                   ex->stream);
+    if (rc) return rc;
+    HIP_CHECK(hipMemcpyAsync(counts, ex->d_ocount, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, ex->stream));
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    int status = ORBX_OK;
+    for (int f = 0; f < n_frames; ++f) {
+        int n = counts[f];
+        if (n > cap_per_frame) { status = ORBX_ERR_CAPACITY; set_error("cap_per_frame smaller than the keypoint count"); n = cap_per_frame; }
+        if (n > 0) {
+            HIP_CHECK(hipMemcpyAsync(kps + (size_t)f * cap_per_frame, ex->d_okp + (size_t)f * G.out_cap, sizeof(orbx_keypoint) * n,
+                                     hipMemcpyDeviceToHost, ex->stream));
+            HIP_CHECK(hipMemcpyAsync(desc + (size_t)f * cap_per_frame * 32, ex->d_odesc + (size_t)f * G.out_cap * 32, (size_t)32 * n,
+                                     hipMemcpyDeviceToHost, ex->stream));
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    return status;
+}
+
+int orbx_extract(orbx_extractor* ex, const uint8_t* image, ptrdiff_t stride, orbx_keypoint* kps, uint8_t* desc, int cap, int* n)
+{
+    if (n) *n = 0;
+    if (!ex || !n) { set_error("orbx_extract: null pointer"); return ORBX_ERR_BAD_ARG; }
+    if (!image) return ORBX_OK; // empty image: silent return, outputs untouched (src/ORBextractor.cc:1045-1046)
+    int32_t count = 0;
+    int rc = orbx_extract_batch(ex, image, stride, 0, 1, kps, desc, &count, cap);
+    *n = count;
+    return rc;
+}
+
+int orbx_pyramid_level_device(orbx_extractor* ex, int frame, int level, const uint8_t** d_roi, int* w, int* h, ptrdiff_t* stride)
+{
+    if (!ex || frame < 0 || frame >= ex->max_batch || level < 0 || level >= ex->geo.nlevels) return ORBX_ERR_BAD_ARG;
+    const LevelGeom& L = ex->geo.lv[level];
+    if (d_roi) *d_roi = ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes + L.roi;
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (stride) *stride = L.stride;
+    return ORBX_OK;
+}
+
+int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride)
+{
+    if (!ex || !dst || frame < 0 || frame >= ex->max_batch || level < 0 || level >= ex->geo.nlevels) return ORBX_ERR_BAD_ARG;
+    const LevelGeom& L = ex->geo.lv[level];
+    if (dst_stride < L.w + 2 * kEdge) return ORBX_ERR_BAD_ARG;
+    HIP_CHECK(hipSetDevice(ex->device));
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    const uint8_t* src = ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes + L.offset + (kRoiX - kEdge);
+    HIP_CHECK(hipMemcpy2D(dst, dst_stride, src, L.stride, L.w + 2 * kEdge, L.rows, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbx_debug_candidates(orbx_extractor* ex, int frame, int level, uint32_t* packed, int cap, int* n)
+{
+    if (!ex || !n || frame < 0 || frame >= ex->max_batch || level < 0 || level >= ex->geo.nlevels) return ORBX_ERR_BAD_ARG;
+    HIP_CHECK(hipSetDevice(ex->device));
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    const Geometry& G = ex->geo;
+    const LevelGeom& L = G.lv[level];
+    std::vector<uint16_t> cnt(L.cell_count);
+    std::vector<uint32_t> slots(std::max(L.cand_cap, 1));
+    HIP_CHECK(hipMemcpy(cnt.data(), ex->d_cellcnt + (size_t)frame * G.cells.size() + L.cell_first, sizeof(uint16_t) * L.cell_count, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(slots.data(), ex->d_cand + (size_t)frame * G.cand_total + L.cand_offset, sizeof(uint32_t) * L.cand_cap, hipMemcpyDeviceToHost));
+    int total = 0;
+    for (int c = 0; c < L.cell_count; ++c) {
+        const CellRec& cr = G.cells[L.cell_first + c];
+        for (int j = 0; j < cnt[c]; ++j) {
+            if (total < cap) packed[total] = slots[cr.slot + j];
+            ++total;
+        }
+    }
+    *n = total;
+    return total > cap ? ORBX_ERR_CAPACITY : ORBX_OK;
+}
+
+int orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, uint32_t* packed, int cap, int* n)
+{
+    if (!ex || !n || frame < 0 || frame >= ex->max_batch || level < 0 || level >= ex->geo.nlevels) return ORBX_ERR_BAD_ARG;
+    HIP_CHECK(hipSetDevice(ex->device));
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    const Geometry& G = ex->geo;
+    const LevelGeom& L = G.lv[level];
+    int32_t cnt = 0;
+    HIP_CHECK(hipMemcpy(&cnt, ex->d_lvlcnt + (size_t)frame * G.nlevels + level, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *n = cnt;
+    if (cnt > cap) return ORBX_ERR_CAPACITY;
+    if (cnt > 0) HIP_CHECK(hipMemcpy(packed, ex->d_lvlkp + (size_t)frame * G.kp_total + L.kp_offset, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbx_distribute_octree(int device, const uint32_t* packed_keys, int n, int minX, int maxX, int minY, int maxY, int N,
+                           uint32_t* out, int cap, int* n_out)
+{
+    if (!n_out || n < 0 || (n > 0 && !packed_keys) || maxX <= minX || maxY <= minY || N < 0 || n >= (1 << 24)) { set_error("orbx_distribute_octree: bad argument"); return ORBX_ERR_BAD_ARG; }
+    const int W = maxX - minX, H = maxY - minY;
+    const int nIni = (int)std::round((float)W / H);
+    if (nIni <= 0 || nIni > kMaxRoots || W >= 4096 || H >= 4096) { set_error("orbx_distribute_octree: unsupported box"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+    const float hX = (float)W / nIni;
+    const int NC = std::max(std::max(N + 3, 4 * nIni) + 9, 64);
+    const size_t lds = ot_lds_bytes(NC, kOctThreads);
+    if (lds > 150 * 1024) { set_error("N too large for the quadtree working set in LDS"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+    int rc = select_device(device);
+    if (rc) return rc;
+    uint32_t *d_keys = nullptr, *d_out = nullptr; uint16_t* d_no = nullptr; int32_t* d_n = nullptr;
+    HIP_CHECK(hipMalloc(&d_keys, sizeof(uint32_t) * std::max(n, 1)));
+    HIP_CHECK(hipMalloc(&d_no, sizeof(uint16_t) * std::max(n, 1)));
+    HIP_CHECK(hipMalloc(&d_out, sizeof(uint32_t) * NC));
+    HIP_CHECK(hipMalloc(&d_n, sizeof(int32_t)));
+    if (n) HIP_CHECK(hipMemcpy(d_keys, packed_keys, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree_single), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(kOctThreads), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC);
+    HIP_CHECK(hipGetLastError());
+    int32_t cnt = 0;
+    HIP_CHECK(hipMemcpy(&cnt, d_n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *n_out = cnt;
+    int status = ORBX_OK;
+    if (cnt > cap) { status = ORBX_ERR_CAPACITY; cnt = cap; }
+    if (cnt > 0) HIP_CHECK(hipMemcpy(out, d_out, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
+    (void)hipFree(d_keys); (void)hipFree(d_no); (void)hipFree(d_out); (void)hipFree(d_n);
+    return status;
+}
+
+int orbx_extractor_set_profiling(orbx_extractor* ex, int on)
+{
+    if (!ex) return ORBX_ERR_BAD_ARG;
+    ex->profiling = on != 0;
+    return ORBX_OK;
+}
+
+int orbx_extractor_stage_ms(orbx_extractor* ex, float* ms)
+{
+    if (!ex || !ms) return ORBX_ERR_BAD_ARG;
+    if (!ex->profiling) { set_error("profiling is off"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(ex->device));
+    HIP_CHECK(hipEventSynchronize(ex->ev[ORBX_STAGE_COUNT]));
+    for (int s = 0; s < ORBX_STAGE_COUNT; ++s) HIP_CHECK(hipEventElapsedTime(&ms[s], ex->ev[s], ex->ev[s + 1]));
+    return ORBX_OK;
+}
+
+} // extern "C"

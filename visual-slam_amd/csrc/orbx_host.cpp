@@ -1,0 +1,429 @@
+// Host-side logic of liborbx that needs no GPU: constructor tables, pyramid/cell geometry, resize
+// coefficient tables, the frame grid, scalar matcher helpers and the synthetic input generators.
+// Compiled with -ffp-contract=off: every float expression rounds per operation, as the reference's
+// C++ does on a baseline x86-64 build.
+#include "orbx_internal.h"
+#include <cmath>
+#include <cfloat>
+#include <cstring>
+#include <climits>
+#include <algorithm>
+
+namespace orbx {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& s) { g_last_error = s; }
+
+static inline int cv_round(double v) { return (int)std::lrint(v); }
+static inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+static inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
+static inline short sat_short(int v) { return (short)std::min(std::max(v, (int)SHRT_MIN), (int)SHRT_MAX); }
+
+// ORBextractor::ORBextractor, src/ORBextractor.cc:409-469
+int build_scale_tables(const orbx_params& p, ScaleTables& t)
+{
+    if (p.nlevels < 1 || p.nlevels > kMaxLevels || p.nfeatures < 0 || !(p.scale_factor > 1.0f)) {
+        set_error("orbx_params: need 1 <= nlevels <= 32, nfeatures >= 0, scale_factor > 1");
+        return ORBX_ERR_BAD_ARG;
+    }
+    const double scaleFactor = p.scale_factor; // the member is a double (include/ORBextractor.h:223)
+    t.nlevels = p.nlevels;
+    t.scale[0] = 1.0f;
+    t.sigma2[0] = 1.0f;
+    for (int i = 1; i < p.nlevels; ++i) {
+        t.scale[i] = (float)(t.scale[i - 1] * scaleFactor);
+        t.sigma2[i] = t.scale[i] * t.scale[i];
+    }
+    for (int i = 0; i < p.nlevels; ++i) {
+        t.inv_scale[i] = 1.0f / t.scale[i];
+        t.inv_sigma2[i] = 1.0f / t.sigma2[i];
+    }
+    const float factor = (float)(1.0f / scaleFactor);
+    float desired = p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p.nlevels));
+    int acc = 0;
+    for (int l = 0; l + 1 < p.nlevels; ++l) {
+        t.quota[l] = cv_round(desired);
+        acc += t.quota[l];
+        desired *= factor;
+    }
+    t.quota[p.nlevels - 1] = std::max(p.nfeatures - acc, 0);
+
+    // circular patch row ends, :453-468
+    int um[kHalfPatch + 2] = {0};
+    const int vmax = cv_floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    const int vmin = cv_ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (int v = 0; v <= vmax; ++v) um[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (um[v0] == um[v0 + 1]) ++v0;
+        um[v] = v0;
+        ++v0;
+    }
+    for (int v = 0; v < 16; ++v) t.umax[v] = um[v];
+    return ORBX_OK;
+}
+
+// Coefficients of cv::resize(INTER_LINEAR) for 8-bit images (OpenCV imgproc, generic path):
+// Q11 weights, source offsets clamped at the right/bottom edge.
+static void build_resize_tables(int sw, int sh, int dw, int dh, std::vector<ResizeX>& rx, std::vector<ResizeY>& ry, int& area2x)
+{
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    const int iscale_x = cv_round(scale_x), iscale_y = cv_round(scale_y);
+    const bool area_fast = std::abs(scale_x - iscale_x) < DBL_EPSILON && std::abs(scale_y - iscale_y) < DBL_EPSILON;
+    area2x = (area_fast && iscale_x == 2 && iscale_y == 2) ? 1 : 0;
+    for (int dx = 0; dx < dw; ++dx) {
+        ResizeX e;
+        if (area2x) { e.sx = 2 * dx; e.a0 = e.a1 = 0; rx.push_back(e); continue; }
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        e.sx = sx;
+        e.a0 = sat_short(cv_round((1.f - fx) * 2048));
+        e.a1 = sat_short(cv_round(fx * 2048));
+        rx.push_back(e);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        ResizeY e;
+        if (area2x) { e.sy0 = (int16_t)(2 * dy); e.sy1 = (int16_t)(2 * dy + 1); e.b0 = e.b1 = 0; ry.push_back(e); continue; }
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        e.b0 = sat_short(cv_round((1.f - fy) * 2048));
+        e.b1 = sat_short(cv_round(fy * 2048));
+        e.sy0 = (int16_t)std::min(std::max(sy, 0), sh - 1);
+        e.sy1 = (int16_t)std::min(std::max(sy + 1, 0), sh - 1);
+        ry.push_back(e);
+    }
+}
+
+int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
+{
+    if (width <= 0 || height <= 0) { set_error("image size must be positive"); return ORBX_ERR_BAD_ARG; }
+    int rc = build_scale_tables(p, g.tables);
+    if (rc) return rc;
+    g.width = width; g.height = height; g.nlevels = p.nlevels;
+    g.lv.assign(p.nlevels, LevelGeom());
+    g.cells.clear(); g.rx.clear(); g.ry.clear();
+    size_t off = 0;
+    int cand_off = 0, kp_off = 0;
+    g.out_cap = 0; g.max_cell_dim = 0;
+    const float W = 30; // src/ORBextractor.cc:768
+    for (int l = 0; l < p.nlevels; ++l) {
+        LevelGeom& L = g.lv[l];
+        const float s = g.tables.inv_scale[l];
+        L.w = cv_round((float)width * s);      // :1111
+        L.h = cv_round((float)height * s);
+        L.scale = g.tables.scale[l];
+        L.kp_size = (float)(int)(kPatch * g.tables.scale[l]);
+        L.quota = g.tables.quota[l];
+        L.rows = L.h + 2 * kEdge;
+        L.stride = (kRoiX + L.w + kEdge + 63) & ~63;
+        L.offset = off;
+        L.roi = off + (size_t)kEdge * L.stride + kRoiX;
+        off += ((size_t)L.stride * L.rows + 255) & ~(size_t)255;
+
+        L.maxBorderX = L.w - kEdge + 3;        // :774-775
+        L.maxBorderY = L.h - kEdge + 3;
+        const float fw = (float)(L.maxBorderX - kMinBorder);
+        const float fh = (float)(L.maxBorderY - kMinBorder);
+        if (!(fw > 0) || !(fh > 0)) { set_error("pyramid level smaller than the 32-pixel border"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+        L.nCols = (int)(fw / W);               // :783-786
+        L.nRows = (int)(fh / W);
+        if (L.nCols <= 0 || L.nRows <= 0) {
+            set_error("pyramid level narrower than 62 pixels: the reference divides by zero (src/ORBextractor.cc:785-786)");
+            return ORBX_ERR_UNSUPPORTED_GEOMETRY;
+        }
+        L.wCell = (int)std::ceil(fw / L.nCols);
+        L.hCell = (int)std::ceil(fh / L.nRows);
+        if (L.maxBorderX - kMinBorder - 4 >= 4096 || L.maxBorderY - kMinBorder - 4 >= 4096) {
+            set_error("level larger than 4128 pixels: packed 12-bit candidate coordinates overflow");
+            return ORBX_ERR_UNSUPPORTED_GEOMETRY;
+        }
+        // DistributeOctTree roots, :542-544
+        L.nIni = (int)std::round((float)(L.maxBorderX - kMinBorder) / (L.maxBorderY - kMinBorder));
+        if (L.nIni <= 0) { set_error("width/height < 0.5: the reference divides by zero (src/ORBextractor.cc:542-544)"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+        if (L.nIni > kMaxRoots) { set_error("width/height > 64 not supported"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+        L.hX = (float)(L.maxBorderX - kMinBorder) / L.nIni;
+
+        // cells, :788-806
+        L.cell_first = (int)g.cells.size();
+        L.cand_offset = cand_off;
+        int slot = 0;
+        for (int i = 0; i < L.nRows; ++i) {
+            const float iniY = (float)(kMinBorder + i * L.hCell);
+            float maxY = iniY + L.hCell + 6;
+            if (iniY >= L.maxBorderY - 3) continue;
+            if (maxY > L.maxBorderY) maxY = (float)L.maxBorderY;
+            for (int j = 0; j < L.nCols; ++j) {
+                const float iniX = (float)(kMinBorder + j * L.wCell);
+                float maxX = iniX + L.wCell + 6;
+                if (iniX >= L.maxBorderX - 6) continue;
+                if (maxX > L.maxBorderX) maxX = (float)L.maxBorderX;
+                const int cw = (int)maxX - (int)iniX - 6, ch = (int)maxY - (int)iniY - 6;
+                if (cw < 1 || ch < 1) continue; // cv::FAST finds nothing in a sub-image narrower than 7
+                CellRec c;
+                c.x0 = (int16_t)iniX; c.y0 = (int16_t)iniY; c.cw = (int16_t)cw; c.ch = (int16_t)ch;
+                c.offx = (int16_t)(j * L.wCell); c.offy = (int16_t)(i * L.hCell);
+                c.level = (int16_t)l; c.pad = 0;
+                c.slot = slot;
+                c.cap = ((cw + 1) / 2) * ((ch + 1) / 2);
+                slot += c.cap;
+                g.max_cell_dim = std::max(g.max_cell_dim, std::max(cw, ch));
+                g.cells.push_back(c);
+            }
+        }
+        L.cell_count = (int)g.cells.size() - L.cell_first;
+        L.cand_cap = slot;
+        cand_off += slot;
+
+        L.kp_cap = std::max(L.quota + 3, 4 * L.nIni) + 1;
+        L.kp_offset = kp_off;
+        kp_off += L.kp_cap;
+        g.out_cap += L.kp_cap;
+
+        L.area2x = 0; L.rx_offset = (int)g.rx.size(); L.ry_offset = (int)g.ry.size();
+        if (l > 0) build_resize_tables(g.lv[l - 1].w, g.lv[l - 1].h, L.w, L.h, g.rx, g.ry, L.area2x);
+    }
+    g.pyr_bytes = off;
+    g.cand_total = cand_off;
+    g.kp_total = kp_off;
+    return ORBX_OK;
+}
+
+// ---- frame grid, src/Frame.cc:230-245, 327-392 ----
+constexpr int kGridCols = 64, kGridRows = 48;
+
+void FrameGrid::build(const orbx_keypoint* k, int n_, float minX_, float maxX_, float minY_, float maxY_)
+{
+    kps = k; n = n_; minX = minX_; maxX = maxX_; minY = minY_; maxY = maxY_;
+    invW = (float)kGridCols / (maxX - minX);
+    invH = (float)kGridRows / (maxY - minY);
+    std::vector<int> cell(n, -1);
+    cell_start.assign(kGridCols * kGridRows + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        const int px = (int)std::round((k[i].x - minX) * invW);   // PosInGrid uses round()
+        const int py = (int)std::round((k[i].y - minY) * invH);
+        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
+        cell[i] = px * kGridRows + py;
+        ++cell_start[cell[i] + 1];
+    }
+    for (size_t c = 1; c < cell_start.size(); ++c) cell_start[c] += cell_start[c - 1];
+    cell_items.assign(std::max(n, 1), 0);
+    std::vector<int> cursor(cell_start.begin(), cell_start.end() - 1);
+    for (int i = 0; i < n; ++i) if (cell[i] >= 0) cell_items[cursor[cell[i]]++] = i;
+}
+
+void FrameGrid::query(float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) const
+{
+    out.clear();
+    const int cx0 = std::max(0, (int)std::floor((x - minX - r) * invW));
+    if (cx0 >= kGridCols) return;
+    const int cx1 = std::min(kGridCols - 1, (int)std::ceil((x - minX + r) * invW));
+    if (cx1 < 0) return;
+    const int cy0 = std::max(0, (int)std::floor((y - minY - r) * invH));
+    if (cy0 >= kGridRows) return;
+    const int cy1 = std::min(kGridRows - 1, (int)std::ceil((y - minY + r) * invH));
+    if (cy1 < 0) return;
+    const bool check = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = cx0; ix <= cx1; ++ix)
+        for (int iy = cy0; iy <= cy1; ++iy) {
+            const int c = ix * kGridRows + iy;
+            for (int j = cell_start[c]; j < cell_start[c + 1]; ++j) {
+                const orbx_keypoint& kp = kps[cell_items[j]];
+                if (check) {
+                    if (kp.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                }
+                if (std::fabs(kp.x - x) < r && std::fabs(kp.y - y) < r) out.push_back(cell_items[j]);
+            }
+        }
+}
+
+// ---- PCG32 (O'Neill), used only by the synthetic generators ----
+struct Pcg32 {
+    uint64_t state, inc;
+    explicit Pcg32(uint64_t seed, uint64_t seq = 54u) { state = 0; inc = (seq << 1u) | 1u; next(); state += seed; next(); }
+    uint32_t next() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+    uint32_t below(uint32_t n) { return next() % n; }
+};
+
+static void paint(uint8_t* img, int w, int h, ptrdiff_t stride, int x0, int y0, int rw, int rh, uint8_t v)
+{
+    const int xa = std::max(x0, 0), xb = std::min(x0 + rw, w), ya = std::max(y0, 0), yb = std::min(y0 + rh, h);
+    for (int y = ya; y < yb; ++y)
+        for (int x = xa; x < xb; ++x) img[y * stride + x] = v;
+}
+
+static void synth(uint32_t frame_index, int w, int h, uint8_t* left, uint8_t* right, ptrdiff_t stride)
+{
+    Pcg32 rng(0x5EED0000ull + frame_index);
+    for (int y = 0; y < h; ++y) {
+        std::memset(left + y * stride, 128, (size_t)w);
+        if (right) std::memset(right + y * stride, 128, (size_t)w);
+    }
+    const int nrect = (int)(((int64_t)w * h) / 200);
+    for (int i = 0; i < nrect; ++i) {
+        const int rw = 6 + (int)rng.below(43), rh = 6 + (int)rng.below(43);
+        const int x0 = (int)rng.below((uint32_t)w), y0 = (int)rng.below((uint32_t)h);
+        const uint8_t v = (uint8_t)(16 + rng.below(225));
+        const int disp = (int)rng.below(41);
+        paint(left, w, h, stride, x0, y0, rw, rh, v);
+        if (right) paint(right, w, h, stride, x0 - disp, y0, rw, rh, v);
+    }
+    for (int pass = 0; pass < (right ? 2 : 1); ++pass) {
+        uint8_t* img = pass ? right : left;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const int v = img[y * stride + x] + (int)rng.below(13) - 6;
+                img[y * stride + x] = (uint8_t)std::min(std::max(v, 0), 255);
+            }
+    }
+}
+
+} // namespace orbx
+
+using namespace orbx;
+
+extern "C" {
+
+const char* orbx_status_string(int s)
+{
+    switch (s) {
+    case ORBX_OK: return "ok";
+    case ORBX_ERR_BAD_ARG: return "bad argument";
+    case ORBX_ERR_UNSUPPORTED_GEOMETRY: return "unsupported image geometry";
+    case ORBX_ERR_HIP: return "HIP runtime error";
+    case ORBX_ERR_CAPACITY: return "output capacity too small";
+    case ORBX_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown status";
+    }
+}
+
+const char* orbx_last_error(void) { return g_last_error.c_str(); }
+
+int orbx_scale_tables(const orbx_params* p, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                      int32_t* features_per_level, int32_t* umax16)
+{
+    if (!p) return ORBX_ERR_BAD_ARG;
+    ScaleTables t;
+    int rc = build_scale_tables(*p, t);
+    if (rc) return rc;
+    for (int i = 0; i < t.nlevels; ++i) {
+        if (scale) scale[i] = t.scale[i];
+        if (inv_scale) inv_scale[i] = t.inv_scale[i];
+        if (sigma2) sigma2[i] = t.sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = t.inv_sigma2[i];
+        if (features_per_level) features_per_level[i] = t.quota[i];
+    }
+    if (umax16) for (int i = 0; i < 16; ++i) umax16[i] = t.umax[i];
+    return ORBX_OK;
+}
+
+int orbx_level_size(const orbx_params* p, int width, int height, int level, int* w, int* h)
+{
+    if (!p || !w || !h) return ORBX_ERR_BAD_ARG;
+    ScaleTables t;
+    int rc = build_scale_tables(*p, t);
+    if (rc) return rc;
+    if (level < 0 || level >= t.nlevels) return ORBX_ERR_BAD_ARG;
+    *w = cv_round((float)width * t.inv_scale[level]);
+    *h = cv_round((float)height * t.inv_scale[level]);
+    return ORBX_OK;
+}
+
+int orbx_keypoint_capacity(const orbx_params* p, int width, int height)
+{
+    if (!p) return -ORBX_ERR_BAD_ARG;
+    Geometry g;
+    int rc = build_geometry(*p, width, height, g);
+    if (rc) return -rc;
+    return g.out_cap;
+}
+
+// ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:1650-1666
+int orbx_descriptor_distance(const uint8_t* a, const uint8_t* b)
+{
+    int d = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint64_t x, y;
+        std::memcpy(&x, a + 8 * i, 8);
+        std::memcpy(&y, b + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+// ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1604-1645
+void orbx_compute_three_maxima(const int32_t* sizes, int L, int* ind1, int* ind2, int* ind3)
+{
+    int m1 = 0, m2 = 0, m3 = 0;
+    for (int i = 0; i < L; ++i) {
+        const int s = sizes[i];
+        if (s > m1) { m3 = m2; m2 = m1; m1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > m2) { m3 = m2; m2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > m3) { m3 = s; *ind3 = i; }
+    }
+    if (m2 < 0.1f * (float)m1) { *ind2 = -1; *ind3 = -1; }
+    else if (m3 < 0.1f * (float)m1) { *ind3 = -1; }
+}
+
+struct orbx_frame_grid { FrameGrid g; };
+
+int orbx_grid_create(const orbx_keypoint* kps, int n, float minX, float maxX, float minY, float maxY, orbx_frame_grid** out)
+{
+    if (!out || n < 0 || (!kps && n > 0) || !(maxX > minX) || !(maxY > minY)) return ORBX_ERR_BAD_ARG;
+    orbx_frame_grid* g = new orbx_frame_grid();
+    g->g.build(kps, n, minX, maxX, minY, maxY);
+    *out = g;
+    return ORBX_OK;
+}
+void orbx_grid_destroy(orbx_frame_grid* g) { delete g; }
+
+int orbx_grid_features_in_area(const orbx_frame_grid* g, float x, float y, float r, int minLevel, int maxLevel,
+                               int32_t* out, int cap, int* n)
+{
+    if (!g || !n) return ORBX_ERR_BAD_ARG;
+    std::vector<int> v;
+    g->g.query(x, y, r, minLevel, maxLevel, v);
+    *n = (int)v.size();
+    if ((int)v.size() > cap) return ORBX_ERR_CAPACITY;
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return ORBX_OK;
+}
+
+void orbx_synth_frame(uint32_t frame_index, int w, int h, uint8_t* out, ptrdiff_t stride)
+{
+    synth(frame_index, w, h, out, nullptr, stride);
+}
+void orbx_synth_stereo(uint32_t frame_index, int w, int h, uint8_t* left, uint8_t* right, ptrdiff_t stride)
+{
+    synth(frame_index, w, h, left, right, stride);
+}
+void orbx_synth_descriptors(uint32_t seed, int64_t n, uint8_t* out)
+{
+    Pcg32 rng(seed);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    for (int64_t i = 0; i < n * 8; ++i) { uint32_t v = rng.next(); std::memcpy(o + i, &v, 4); }
+}
+void orbx_synth_queries(uint32_t seed, const uint8_t* map, int64_t n_map, int nq, uint8_t* out, int64_t* src_idx)
+{
+    Pcg32 rng(seed);
+    for (int i = 0; i < nq; ++i) {
+        const int64_t r = (int64_t)((((uint64_t)rng.next() << 32) | rng.next()) % (uint64_t)n_map);
+        if (src_idx) src_idx[i] = r;
+        std::memcpy(out + (size_t)i * 32, map + (size_t)r * 32, 32);
+        for (int b = 0; b < 256; ++b)
+            if (rng.below(100) < 8) out[(size_t)i * 32 + (b >> 3)] ^= (uint8_t)(1u << (b & 7));
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,89 @@
+// Internal declarations shared by the host-only and the HIP translation units of liborbx.
+#pragma once
+#include "../../include/orbx.h"
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+
+namespace orbx {
+
+constexpr int kEdge = 19;        // EDGE_THRESHOLD, src/ORBextractor.cc:73
+constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE, src/ORBextractor.cc:72
+constexpr int kPatch = 31;       // PATCH_SIZE, src/ORBextractor.cc:71
+constexpr int kMinBorder = 16;   // EDGE_THRESHOLD-3, src/ORBextractor.cc:772
+constexpr int kMaxLevels = 32;
+constexpr int kRoiX = 32;        // column of the ROI origin inside a padded row (keeps ROI rows 32-byte aligned)
+constexpr int kMaxRoots = 64;
+
+void set_error(const std::string& s);
+
+// Constructor tables of ORBextractor (src/ORBextractor.cc:409-469)
+struct ScaleTables {
+    int nlevels = 0;
+    float scale[kMaxLevels], inv_scale[kMaxLevels], sigma2[kMaxLevels], inv_sigma2[kMaxLevels];
+    int quota[kMaxLevels];
+    int umax[16];
+};
+int build_scale_tables(const orbx_params& p, ScaleTables& t);
+
+// One FAST cell of ComputeKeyPointsOctTree (src/ORBextractor.cc:788-828), in ROI coordinates.
+struct CellRec {
+    int16_t x0, y0;      // top-left of the cell sub-image (iniX, iniY)
+    int16_t cw, ch;      // size of the detection area (sub-image size minus the 3-pixel ring on each side)
+    int16_t offx, offy;  // j*wCell, i*hCell: added to cell-local coordinates (:821-822)
+    int16_t level, pad;
+    int32_t slot;        // first candidate slot of this cell inside its level's slot array
+    int32_t cap;         // slots reserved: ceil(cw/2)*ceil(ch/2), the most strict local maxima a cw x ch area can hold
+};
+
+struct ResizeX { int32_t sx; int16_t a0, a1; };          // source column and Q11 weights of one destination column
+struct ResizeY { int16_t sy0, sy1; int16_t b0, b1; };    // clamped source rows and Q11 weights of one destination row
+
+struct LevelGeom {
+    int w, h;               // ROI size (src/ORBextractor.cc:1111)
+    int stride, rows;       // padded buffer: rows = h+38, stride bytes per row
+    size_t offset;          // byte offset of the padded buffer inside one frame's pyramid block
+    size_t roi;             // byte offset of the ROI origin inside one frame's pyramid block
+    int maxBorderX, maxBorderY, nCols, nRows, wCell, hCell;
+    int cell_first, cell_count;
+    int cand_offset, cand_cap;   // candidate slots of this level inside one frame's slot array (u32 units)
+    int quota;              // mnFeaturesPerLevel[level]
+    int nIni; float hX;     // DistributeOctTree roots (src/ORBextractor.cc:542-544)
+    int kp_offset, kp_cap;  // selected-keypoint slots of this level inside one frame's per-level array
+    int area2x;             // resize from the previous level is an exact 2x2 decimation (OpenCV reroutes to INTER_AREA)
+    int rx_offset, ry_offset; // offsets into the ResizeX / ResizeY tables
+    float scale;            // mvScaleFactor[level]
+    float kp_size;          // (float)(int)(31*scale), src/ORBextractor.cc:836,845
+};
+
+struct Geometry {
+    int width = 0, height = 0, nlevels = 0;
+    ScaleTables tables;
+    std::vector<LevelGeom> lv;
+    std::vector<CellRec> cells;
+    std::vector<ResizeX> rx;
+    std::vector<ResizeY> ry;
+    size_t pyr_bytes = 0;     // one frame's pyramid block
+    int cand_total = 0;       // one frame's candidate slots (u32)
+    int kp_total = 0;         // one frame's per-level selected-keypoint slots
+    int out_cap = 0;          // sum over levels of kp_cap
+    int max_cell_dim = 0;
+};
+// returns ORBX_OK or ORBX_ERR_UNSUPPORTED_GEOMETRY / ORBX_ERR_BAD_ARG
+int build_geometry(const orbx_params& p, int width, int height, Geometry& g);
+
+// 64x48 frame grid (src/Frame.cc:230-245, 327-392)
+struct FrameGrid {
+    const orbx_keypoint* kps; int n;
+    float minX, maxX, minY, maxY, invW, invH;
+    std::vector<int> cell_start, cell_items;
+    void build(const orbx_keypoint* k, int n_, float minX_, float maxX_, float minY_, float maxY_);
+    void query(float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) const;
+};
+
+// device CSR distance kernel driver (defined in orbx_match.hip); host pointers in/out
+int csr_distances(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                  const int32_t* rowptr, const int32_t* cand, int32_t* dist_out);
+
+} // namespace orbx

@@ -1,0 +1,428 @@
+// MI355X (gfx950) kernels of the descriptor matcher: the 256-bit Hamming loops of ORBmatcher
+// (src/ORBmatcher.cc:1650-1666 DescriptorDistance and the best / second-best bookkeeping of the
+// Search* routines) and of Frame::ComputeStereoMatches (src/Frame.cc:466-549).
+//
+// Distances are 8 x (v_xor_b32 + v_bcnt_u32_b32) per pair; nothing here is a dense contraction, so
+// no MFMA.  The brute-force kernel keeps queries in VGPRs and streams map rows through scalar
+// registers (every lane of a wave compares against the same row), so a pair costs 16 vector
+// lane-operations plus three for the running best / second-best.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include "orbx_internal.h"
+
+using namespace orbx;
+
+#define HIP_CHECK(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+            return ORBX_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+constexpr int kIdxBits = 22;                       // row index inside a chunk
+constexpr uint32_t kKeyInit = 256u << kIdxBits;    // distance 256, never beaten by a real row (strict '<')
+constexpr int kQPT = 2;                            // queries per thread
+constexpr int kBlock = 256;
+
+struct Part { uint32_t best, second; };            // packed keys: distance << 22 | row-in-chunk
+
+__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c)
+{
+    return max(min(a, b), min(max(a, b), c));      // folds to v_med3_u32
+}
+
+// grid: (chunks, query tiles).  Thread t of tile y owns queries y*512 + t and y*512 + 256 + t.
+__global__ __launch_bounds__(kBlock) void k_best2(const uint32_t* __restrict__ q, int nq,
+                                                  const uint32_t* __restrict__ t, long long nt,
+                                                  int rows_per_chunk, Part* __restrict__ parts)
+{
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.y * (kBlock * kQPT) + tid;
+    uint32_t qv[kQPT][8];
+    uint32_t best[kQPT], second[kQPT];
+#pragma unroll
+    for (int j = 0; j < kQPT; ++j) {
+        const int qi = min(q0 + j * kBlock, nq - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[j][i] = q[(size_t)qi * 8 + i];
+        best[j] = kKeyInit; second[j] = kKeyInit;
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_chunk;
+    const int nrows = (int)min((long long)rows_per_chunk, nt - r0);
+    const uint32_t* row = t + (size_t)r0 * 8;
+#pragma unroll 4
+    for (int r = 0; r < nrows; ++r, row += 8) {
+        uint32_t m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = row[i];          // wave-uniform address: scalar load
+#pragma unroll
+        for (int j = 0; j < kQPT; ++j) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d += __popc(qv[j][i] ^ m[i]);
+            const uint32_t key = (d << kIdxBits) + (uint32_t)r;
+            second[j] = med3u(best[j], second[j], key);
+            best[j] = min(best[j], key);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kQPT; ++j) {
+        const int qi = q0 + j * kBlock;
+        if (qi < nq) { Part p; p.best = best[j]; p.second = second[j]; parts[(size_t)blockIdx.x * nq + qi] = p; }
+    }
+}
+
+// one thread per query: fold the per-chunk partial results in chunk (= index) order
+__global__ __launch_bounds__(256) void k_best2_fold(const Part* __restrict__ parts, int nchunks, int nq, int rows_per_chunk,
+                                                    long long index_base, orbx_best2* __restrict__ out)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    int best = 256, second = 256;
+    long long idx = -1;
+    for (int c = 0; c < nchunks; ++c) {
+        const Part p = parts[(size_t)c * nq + qi];
+        const int b = (int)(p.best >> kIdxBits), s = (int)(p.second >> kIdxBits);
+        if (b < best) {
+            second = min(best, s);
+            best = b;
+            idx = index_base + (long long)c * rows_per_chunk + (long long)(p.best & ((1u << kIdxBits) - 1u));
+        } else {
+            second = min(second, b);
+        }
+        second = min(second, s);
+    }
+    orbx_best2 o;
+    o.best = best; o.best_idx = (int32_t)idx; o.second = second; o.pad = 0;
+    out[qi] = o;
+}
+
+// merge shard results (shard-major): lowest distance, then lowest global index; second = second
+// smallest of the union, which is what one sequential pass over the whole set yields
+__global__ __launch_bounds__(256) void k_best2_merge(const orbx_best2* __restrict__ parts, int n_parts, int nq, orbx_best2* __restrict__ out)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    int best = 256, second = 256, idx = -1;
+    for (int p = 0; p < n_parts; ++p) {
+        const orbx_best2 r = parts[(size_t)p * nq + qi];
+        if (r.best_idx < 0) continue;
+        if (r.best < best || (r.best == best && r.best_idx < idx)) {
+            second = min(second, best);
+            best = r.best; idx = r.best_idx;
+        } else {
+            second = min(second, r.best);
+        }
+        second = min(second, r.second);
+    }
+    orbx_best2 o;
+    o.best = best; o.best_idx = idx; o.second = second; o.pad = 0;
+    out[qi] = o;
+}
+
+// CSR distances: one wavefront per query row
+__global__ __launch_bounds__(256) void k_csr_dist(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ t,
+                                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cand,
+                                                  int32_t* __restrict__ dist)
+{
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    uint32_t qv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = q[(size_t)qi * 8 + i];
+    const int b = rowptr[qi], e = rowptr[qi + 1];
+    for (int c = b + lane; c < e; c += 64) {
+        const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)cand[c] * 8);
+        const uint4 lo = tp[0], hi = tp[1];
+        int d = __popc(qv[0] ^ lo.x) + __popc(qv[1] ^ lo.y) + __popc(qv[2] ^ lo.z) + __popc(qv[3] ^ lo.w) +
+                __popc(qv[4] ^ hi.x) + __popc(qv[5] ^ hi.y) + __popc(qv[6] ^ hi.z) + __popc(qv[7] ^ hi.w);
+        dist[c] = d;
+    }
+}
+
+// Stereo row-band search (src/Frame.cc:476-549): one thread per left keypoint, right keypoints of
+// the pair staged in LDS and walked in index order (the order of vRowIndices[row]).
+constexpr int kStereoChunk = 512;
+__global__ __launch_bounds__(256) void k_stereo(const orbx_keypoint* __restrict__ kl, const uint32_t* __restrict__ dl, const int32_t* __restrict__ nl_arr,
+                                                const orbx_keypoint* __restrict__ kr, const uint32_t* __restrict__ dr, const int32_t* __restrict__ nr_arr,
+                                                int cap, int nl_fixed, int nr_fixed,
+                                                const float* __restrict__ scale, int n_rows, float min_d, float max_d,
+                                                int32_t* __restrict__ best_dist, int32_t* __restrict__ best_idx)
+{
+    __shared__ float s_x[kStereoChunk];
+    __shared__ int s_minr[kStereoChunk], s_maxr[kStereoChunk], s_oct[kStereoChunk];
+    __shared__ uint32_t s_d[kStereoChunk * 8];
+    const int pair = blockIdx.y;
+    const int nl = nl_arr ? min(nl_arr[pair], cap) : nl_fixed;
+    const int nr = nr_arr ? min(nr_arr[pair], cap) : nr_fixed;
+    const size_t base = (size_t)pair * cap;
+    const int iL = blockIdx.x * 256 + threadIdx.x;
+    const bool active = iL < nl;
+    uint32_t qv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int row = -1, levelL = 0;
+    float minU = 0.f, maxU = -1.f;
+    if (active) {
+        const orbx_keypoint k = kl[base + iL];
+        levelL = k.octave;
+        row = (int)k.y;
+        minU = __fsub_rn(k.x, max_d);
+        maxU = __fsub_rn(k.x, min_d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = dl[(base + iL) * 8 + i];
+    }
+    const bool rowok = active && row >= 0 && row < n_rows;
+    uint32_t best = (100u << 16);
+    bool anyRow = false;
+    for (int c0 = 0; c0 < nr; c0 += kStereoChunk) {
+        const int m = min(kStereoChunk, nr - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += 256) {
+            const orbx_keypoint k = kr[base + c0 + i];
+            const float r = __fmul_rn(2.0f, scale[k.octave]);
+            s_x[i] = k.x;
+            s_maxr[i] = (int)ceilf(__fadd_rn(k.y, r));
+            s_minr[i] = (int)floorf(__fsub_rn(k.y, r));
+            s_oct[i] = k.octave;
+        }
+        for (int i = threadIdx.x; i < m * 8; i += 256) s_d[i] = dr[(base + c0) * 8 + i];
+        __syncthreads();
+        if (rowok) {
+            for (int i = 0; i < m; ++i) {
+                if (row < s_minr[i] || row > s_maxr[i]) continue;
+                anyRow = true;
+                const int o = s_oct[i];
+                if (o < levelL - 1 || o > levelL + 1) continue;
+                const float uR = s_x[i];
+                if (uR >= minU && uR <= maxU) {
+                    uint32_t d = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) d += __popc(qv[w] ^ s_d[i * 8 + w]);
+                    best = min(best, (d << 16) | (uint32_t)(c0 + i));
+                }
+            }
+        }
+    }
+    if (active) {
+        const bool skipped = !rowok || !anyRow || (maxU < 0);
+        best_dist[base + iL] = skipped ? -1 : (int)(best >> 16);
+        best_idx[base + iL] = skipped ? -1 : (int)(best & 0xFFFF);
+    }
+}
+
+} // namespace
+
+struct orbx_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* ws = nullptr; size_t ws_bytes = 0;       // partial results of the brute-force kernel
+    void* stage[8] = {}; size_t stage_bytes[8] = {}; // staging buffers of the host entry points
+};
+
+static int reserve(void** p, size_t* have, size_t need)
+{
+    if (*have >= need && *p) return ORBX_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *have = 0;
+    HIP_CHECK(hipMalloc(p, std::max<size_t>(need, 256)));
+    *have = std::max<size_t>(need, 256);
+    return ORBX_OK;
+}
+
+static void chunking(int nq, int64_t nt, int& rows_per_chunk, int& nchunks)
+{
+    const int qtiles = (nq + kBlock * kQPT - 1) / (kBlock * kQPT);
+    int64_t want = std::max<int64_t>(1, 4096 / std::max(qtiles, 1));     // enough workgroups to fill 256 CUs several times
+    int64_t rpc = (nt + want - 1) / want;
+    rpc = std::max<int64_t>(rpc, 256);
+    rpc = std::min<int64_t>(rpc, (1 << kIdxBits));
+    rows_per_chunk = (int)rpc;
+    nchunks = (int)((nt + rpc - 1) / rpc);
+    if (nchunks < 1) nchunks = 1;
+}
+
+extern "C" {
+
+int orbx_matcher_create(int device, orbx_matcher** out)
+{
+    if (!out) return ORBX_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return ORBX_ERR_NO_DEVICE; }
+    if (device >= count) { set_error("device index out of range"); return ORBX_ERR_BAD_ARG; }
+    if (device >= 0) HIP_CHECK(hipSetDevice(device));
+    orbx_matcher* m = new orbx_matcher();
+    HIP_CHECK(hipGetDevice(&m->device));
+    HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    *out = m;
+    return ORBX_OK;
+}
+
+void orbx_matcher_destroy(orbx_matcher* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->ws) (void)hipFree(m->ws);
+    for (void* p : m->stage) if (p) (void)hipFree(p);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int64_t orbx_hamming_best2_workspace_bytes(int nq, int64_t nt)
+{
+    int rpc, nch;
+    chunking(nq, nt, rpc, nch);
+    return (int64_t)sizeof(Part) * nch * nq;
+}
+
+int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt, int64_t index_base,
+                              orbx_best2* d_out, void* stream)
+{
+    if (!m || !d_q || !d_out || nq < 1 || nt < 0 || (nt > 0 && !d_t)) { set_error("orbx_hamming_best2_device: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (index_base + nt > 0x7FFFFFFFLL) { set_error("global row index exceeds int32"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    int rpc, nch;
+    chunking(nq, nt, rpc, nch);
+    int rc = reserve(&m->ws, &m->ws_bytes, sizeof(Part) * (size_t)nch * nq);
+    if (rc) return rc;
+    const int qtiles = (nq + kBlock * kQPT - 1) / (kBlock * kQPT);
+    if (nt == 0) nch = 0;
+    if (nch > 0)
+        hipLaunchKernelGGL(k_best2, dim3(nch, qtiles), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(d_q), nq,
+                           reinterpret_cast<const uint32_t*>(d_t), (long long)nt, rpc, reinterpret_cast<Part*>(m->ws));
+    hipLaunchKernelGGL(k_best2_fold, dim3((nq + 255) / 256), dim3(256), 0, st, reinterpret_cast<const Part*>(m->ws), nch, nq, rpc,
+                       (long long)index_base, d_out);
+    HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_best2_merge_device(orbx_matcher* m, const orbx_best2* d_parts, int n_parts, int nq, orbx_best2* d_out, void* stream)
+{
+    if (!m || !d_parts || !d_out || n_parts < 1 || nq < 1) { set_error("orbx_best2_merge_device: bad argument"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    hipLaunchKernelGGL(k_best2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, d_parts, n_parts, nq, d_out);
+    HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_hamming_best2(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int64_t nt, orbx_best2* out)
+{
+    if (!m || !q || !out || nq < 1 || nt < 0 || (nt > 0 && !t)) { set_error("orbx_hamming_best2: bad argument"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    if ((rc = reserve(&m->stage[0], &m->stage_bytes[0], (size_t)nq * 32))) return rc;
+    if ((rc = reserve(&m->stage[1], &m->stage_bytes[1], (size_t)nt * 32))) return rc;
+    if ((rc = reserve(&m->stage[2], &m->stage_bytes[2], sizeof(orbx_best2) * (size_t)nq))) return rc;
+    HIP_CHECK(hipMemcpyAsync(m->stage[0], q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    if (nt) HIP_CHECK(hipMemcpyAsync(m->stage[1], t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+    rc = orbx_hamming_best2_device(m, (const uint8_t*)m->stage[0], nq, (const uint8_t*)m->stage[1], nt, 0, (orbx_best2*)m->stage[2], m->stream);
+    if (rc) return rc;
+    HIP_CHECK(hipMemcpyAsync(out, m->stage[2], sizeof(orbx_best2) * (size_t)nq, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbx_hamming_csr(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, const int32_t* rowptr, const int32_t* cand,
+                     int32_t* dist_out)
+{
+    if (!m || nq < 0 || nt < 0 || !rowptr) { set_error("orbx_hamming_csr: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (nq == 0) return ORBX_OK;
+    const int total = rowptr[nq];
+    if (total == 0) return ORBX_OK;
+    if (!q || !t || !cand || !dist_out) { set_error("orbx_hamming_csr: null pointer"); return ORBX_ERR_BAD_ARG; }
+    for (int i = 0; i < nq; ++i) if (rowptr[i] > rowptr[i + 1] || rowptr[i] < 0) { set_error("rowptr not monotone"); return ORBX_ERR_BAD_ARG; }
+    for (int c = 0; c < total; ++c) if (cand[c] < 0 || cand[c] >= nt) { set_error("candidate index out of range"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    if ((rc = reserve(&m->stage[0], &m->stage_bytes[0], (size_t)nq * 32))) return rc;
+    if ((rc = reserve(&m->stage[1], &m->stage_bytes[1], (size_t)nt * 32))) return rc;
+    if ((rc = reserve(&m->stage[3], &m->stage_bytes[3], sizeof(int32_t) * (size_t)(nq + 1)))) return rc;
+    if ((rc = reserve(&m->stage[4], &m->stage_bytes[4], sizeof(int32_t) * (size_t)total))) return rc;
+    if ((rc = reserve(&m->stage[5], &m->stage_bytes[5], sizeof(int32_t) * (size_t)total))) return rc;
+    HIP_CHECK(hipMemcpyAsync(m->stage[0], q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(m->stage[1], t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(m->stage[3], rowptr, sizeof(int32_t) * (size_t)(nq + 1), hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(m->stage[4], cand, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_csr_dist, dim3((nq + 3) / 4), dim3(256), 0, m->stream, (const uint32_t*)m->stage[0], nq, (const uint32_t*)m->stage[1],
+                       (const int32_t*)m->stage[3], (const int32_t*)m->stage[4], (int32_t*)m->stage[5]);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(dist_out, m->stage[5], sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbx_stereo_match_batch_device(orbx_matcher* m, const orbx_keypoint* d_kl, const uint8_t* d_dl, const int32_t* d_nl,
+                                   const orbx_keypoint* d_kr, const uint8_t* d_dr, const int32_t* d_nr, int cap_per_frame, int n_pairs,
+                                   const float* scale_factors, int nlevels, int n_rows, float min_d, float max_d,
+                                   int32_t* d_best_dist, int32_t* d_best_idx, void* stream)
+{
+    if (!m || !d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !scale_factors || !d_best_dist || !d_best_idx ||
+        cap_per_frame < 1 || cap_per_frame > 65535 || n_pairs < 1 || nlevels < 1 || nlevels > kMaxLevels) {
+        set_error("orbx_stereo_match_batch_device: bad argument"); return ORBX_ERR_BAD_ARG;
+    }
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    int rc;
+    if ((rc = reserve(&m->stage[6], &m->stage_bytes[6], sizeof(float) * kMaxLevels))) return rc;
+    HIP_CHECK(hipMemcpyAsync(m->stage[6], scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_stereo, dim3((cap_per_frame + 255) / 256, n_pairs), dim3(256), 0, st, d_kl, (const uint32_t*)d_dl, d_nl,
+                       d_kr, (const uint32_t*)d_dr, d_nr, cap_per_frame, 0, 0, (const float*)m->stage[6], n_rows, min_d, max_d,
+                       d_best_dist, d_best_idx);
+    HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_stereo_match(orbx_matcher* m, const orbx_keypoint* kl, const uint8_t* dl, int nl, const orbx_keypoint* kr, const uint8_t* dr, int nr,
+                      const float* scale_factors, int nlevels, int n_rows, float min_d, float max_d, int32_t* best_dist, int32_t* best_idx)
+{
+    if (!m || nl < 0 || nr < 0 || !scale_factors || nlevels < 1 || nlevels > kMaxLevels || nr > 65535) { set_error("orbx_stereo_match: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (nl == 0) return ORBX_OK;
+    if (!kl || !dl || !best_dist || !best_idx || (nr > 0 && (!kr || !dr))) { set_error("orbx_stereo_match: null pointer"); return ORBX_ERR_BAD_ARG; }
+    for (int i = 0; i < nl; ++i) if (kl[i].octave < 0 || kl[i].octave >= nlevels) { set_error("left octave out of range"); return ORBX_ERR_BAD_ARG; }
+    for (int i = 0; i < nr; ++i) if (kr[i].octave < 0 || kr[i].octave >= nlevels) { set_error("right octave out of range"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(m->device));
+    const int cap = std::max(nl, std::max(nr, 1));
+    int rc;
+    if ((rc = reserve(&m->stage[0], &m->stage_bytes[0], sizeof(orbx_keypoint) * (size_t)cap))) return rc;
+    if ((rc = reserve(&m->stage[1], &m->stage_bytes[1], (size_t)cap * 32))) return rc;
+    if ((rc = reserve(&m->stage[2], &m->stage_bytes[2], sizeof(orbx_keypoint) * (size_t)cap))) return rc;
+    if ((rc = reserve(&m->stage[3], &m->stage_bytes[3], (size_t)cap * 32))) return rc;
+    if ((rc = reserve(&m->stage[4], &m->stage_bytes[4], sizeof(int32_t) * (size_t)cap))) return rc;
+    if ((rc = reserve(&m->stage[5], &m->stage_bytes[5], sizeof(int32_t) * (size_t)cap))) return rc;
+    if ((rc = reserve(&m->stage[6], &m->stage_bytes[6], sizeof(float) * kMaxLevels))) return rc;
+    HIP_CHECK(hipMemcpyAsync(m->stage[0], kl, sizeof(orbx_keypoint) * (size_t)nl, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(m->stage[1], dl, (size_t)nl * 32, hipMemcpyHostToDevice, m->stream));
+    if (nr) {
+        HIP_CHECK(hipMemcpyAsync(m->stage[2], kr, sizeof(orbx_keypoint) * (size_t)nr, hipMemcpyHostToDevice, m->stream));
+        HIP_CHECK(hipMemcpyAsync(m->stage[3], dr, (size_t)nr * 32, hipMemcpyHostToDevice, m->stream));
+    }
+    HIP_CHECK(hipMemcpyAsync(m->stage[6], scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_stereo, dim3((nl + 255) / 256, 1), dim3(256), 0, m->stream, (const orbx_keypoint*)m->stage[0], (const uint32_t*)m->stage[1],
+                       (const int32_t*)nullptr, (const orbx_keypoint*)m->stage[2], (const uint32_t*)m->stage[3], (const int32_t*)nullptr, cap, nl, nr,
+                       (const float*)m->stage[6], n_rows, min_d, max_d, (int32_t*)m->stage[4], (int32_t*)m->stage[5]);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(best_dist, m->stage[4], sizeof(int32_t) * (size_t)nl, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipMemcpyAsync(best_idx, m->stage[5], sizeof(int32_t) * (size_t)nl, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+} // extern "C"
+
+namespace orbx {
+int csr_distances(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, const int32_t* rowptr, const int32_t* cand, int32_t* dist_out)
+{
+    return orbx_hamming_csr(m, q, nq, t, nt, rowptr, cand, dist_out);
+}
+}
