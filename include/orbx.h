@@ -11,7 +11,7 @@
  *  - every function returns an orbx_status (0 = ok) unless it is a pure scalar helper;
  *  - "host" entry points take host pointers and are synchronous;
  *  - "*_device" entry points take device pointers (HBM resident), enqueue on the given
- *    hipStream_t (passed as void*, NULL = the context's own stream) and do not synchronise;
+ *    hipStream_t (passed as void*, NULL = the HIP default stream) and do not synchronise;
  *  - a context (extractor / matcher) owns one HIP stream and its workspace; distinct contexts
  *    may be used concurrently from different host threads, one context is not re-entrant
  *    (same rule as the reference: src/Frame.cc:78-81 runs two extractor instances in two threads).

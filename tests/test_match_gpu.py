@@ -23,6 +23,20 @@ def stereo_features(vsa, oracle):
     return w, h, kl, dl, kr, dr
 
 
+@pytest.fixture(scope="module")
+def motion_features(vsa, oracle):
+    """Two views related by a small translation plus fresh noise: many true correspondences."""
+    w, h = 640, 480
+    a = vsa.synth_frame(12, w, h)
+    rng = np.random.default_rng(1)
+    b = np.roll(a, (3, 5), axis=(0, 1)).astype(np.int32) + rng.integers(-2, 3, a.shape)
+    b = np.clip(b, 0, 255).astype(np.uint8)
+    oex = oracle.Extractor(oracle.make_params(2000))
+    k1, d1 = oex.extract(a)
+    k2, d2 = oex.extract(b)
+    return w, h, k1, d1, k2, d2
+
+
 def eq_best2(a, b):
     return all(np.array_equal(a[f], b[f]) for f in ("best", "best_idx", "second"))
 
@@ -81,8 +95,8 @@ def test_csr_distances(vsa, oracle, matcher):
     assert np.array_equal(dist, want)
 
 
-def test_search_for_initialization(vsa, oracle, matcher, stereo_features):
-    w, h, kl, dl, kr, dr = stereo_features
+def test_search_for_initialization(vsa, oracle, matcher, motion_features):
+    w, h, kl, dl, kr, dr = motion_features
     bounds = (0.0, float(w), 0.0, float(h))
     prev = np.stack([kl["x"], kl["y"]], 1).astype(np.float32)
     for check_ori in (True, False):
@@ -95,14 +109,14 @@ def test_search_for_initialization(vsa, oracle, matcher, stereo_features):
     assert g[1] > 20 and (g[0] >= 0).sum() == g[1]
 
 
-def test_search_by_projection_variants(vsa, oracle, matcher, stereo_features):
-    w, h, kl, dl, kr, dr = stereo_features
+def test_search_by_projection_variants(vsa, oracle, matcher, motion_features):
+    w, h, kl, dl, kr, dr = motion_features
     rng = np.random.default_rng(9)
     bounds = (0.0, float(w), 0.0, float(h))
     scale = vsa.scale_tables(vsa.make_params())["scale"]
     nq = len(kl)
-    qu = kl["x"] - rng.uniform(0, 30, nq).astype(np.float32)
-    qv = kl["y"] + rng.uniform(-1.5, 1.5, nq).astype(np.float32)
+    qu = kl["x"] + 5.0 + rng.uniform(-3, 3, nq).astype(np.float32)
+    qv = kl["y"] + 3.0 + rng.uniform(-3, 3, nq).astype(np.float32)
     lvl = kl["octave"].astype(np.int32)
     uright = np.where(rng.random(len(kr)) < 0.5, kr["x"] - 5.0, -1.0).astype(np.float32)
     qur = (qu - 5.0).astype(np.float32)

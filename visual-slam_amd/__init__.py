@@ -32,6 +32,13 @@ class OrbxError(RuntimeError):
 
 
 def _load():
+    # PyTorch bundles its own HIP runtime under the same soname as /opt/rocm's.  Whichever is mapped
+    # first serves the whole process, and torch cannot initialise on top of the system one, so when
+    # torch is installed let it load first; liborbx then binds to that runtime as well.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C visual-slam_amd/csrc) first; there is no fallback path")

@@ -644,7 +644,7 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     if (n_frames < 1 || n_frames > ex->max_batch) { set_error("n_frames outside [1, max_batch]"); return ORBX_ERR_BAD_ARG; }
     if (row_stride < ex->geo.width || cap_per_frame < 1) { set_error("row_stride < width or cap_per_frame < 1"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipSetDevice(ex->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ex->stream;
+    hipStream_t st = (hipStream_t)stream;
     const Geometry& G = ex->geo;
     const int B = n_frames;
     const bool prof = ex->profiling;

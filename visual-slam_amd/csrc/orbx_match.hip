@@ -290,7 +290,7 @@ int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const
     if (!m || !d_q || !d_out || nq < 1 || nt < 0 || (nt > 0 && !d_t)) { set_error("orbx_hamming_best2_device: bad argument"); return ORBX_ERR_BAD_ARG; }
     if (index_base + nt > 0x7FFFFFFFLL) { set_error("global row index exceeds int32"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    hipStream_t st = (hipStream_t)stream;
     int rpc, nch;
     chunking(nq, nt, rpc, nch);
     int rc = reserve(&m->ws, &m->ws_bytes, sizeof(Part) * (size_t)nch * nq);
@@ -310,7 +310,7 @@ int orbx_best2_merge_device(orbx_matcher* m, const orbx_best2* d_parts, int n_pa
 {
     if (!m || !d_parts || !d_out || n_parts < 1 || nq < 1) { set_error("orbx_best2_merge_device: bad argument"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_best2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, d_parts, n_parts, nq, d_out);
     HIP_CHECK(hipGetLastError());
     return ORBX_OK;
@@ -372,7 +372,7 @@ int orbx_stereo_match_batch_device(orbx_matcher* m, const orbx_keypoint* d_kl, c
         set_error("orbx_stereo_match_batch_device: bad argument"); return ORBX_ERR_BAD_ARG;
     }
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = reserve(&m->stage[6], &m->stage_bytes[6], sizeof(float) * kMaxLevels))) return rc;
     HIP_CHECK(hipMemcpyAsync(m->stage[6], scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, st));
