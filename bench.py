@@ -148,7 +148,7 @@ def main():
         table = torch.from_numpy(table_np).to(dev)
         q = torch.from_numpy(q_np).to(dev)
         part = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
-        gathered = torch.zeros((n_gpus, nq, 4), dtype=torch.int32, device=dev)
+        gathered = torch.zeros((n_gpus * nq, 4), dtype=torch.int32, device=dev)
         merged = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
 
         def match_step():

@@ -134,6 +134,8 @@ int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const
 /* Merge per-shard results (ranks x nq records, shard-major; best_idx already global) into nq records:
  * the step after the RCCL all-gather when the map is sharded over GPUs. */
 int orbx_best2_merge_device(orbx_matcher* m, const orbx_best2* d_parts, int n_parts, int nq, orbx_best2* d_out, void* stream);
+/* The same merge on host arrays (shards gathered over a network instead of xGMI). */
+int orbx_best2_merge(const orbx_best2* parts, int n_parts, int nq, orbx_best2* out);
 /* Bytes of scratch the brute-force kernel keeps per call, for sizing checks. */
 int64_t orbx_hamming_best2_workspace_bytes(int nq, int64_t nt);
 

@@ -1,0 +1,215 @@
+"""CPU tests of the oracle itself: the known-answer values that can be derived by reading the reference
+(no golden vectors ship with it) and the hand-computable cases of the OpenCV primitives."""
+import numpy as np
+import pytest
+
+
+def test_quotas(oracle):
+    cases = {
+        (1000, 1.2, 8): [217, 181, 151, 126, 105, 87, 73, 60],
+        (2000, 1.2, 8): [434, 362, 302, 251, 209, 175, 145, 122],
+        (1200, 1.2, 8): [261, 217, 181, 151, 126, 105, 87, 72],
+        (8000, 1.2, 12): [1502, 1251, 1043, 869, 724, 604, 503, 419, 349, 291, 243, 202],
+    }
+    for (nf, sf, nl), want in cases.items():
+        t = oracle.Extractor(oracle.make_params(nf, sf, nl)).tables()
+        assert t["quota"].tolist() == want
+        assert t["quota"].sum() == nf
+
+
+def test_umax_and_scale_tables(oracle):
+    t = oracle.Extractor(oracle.make_params(1000, 1.2, 12)).tables()
+    assert t["umax"].tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert 2 * sum(2 * u + 1 for u in t["umax"][1:]) + 2 * t["umax"][0] + 1 == 749
+    want = [1.0, 1.2000000477, 1.4400000572, 1.7280001640, 2.0736002922, 2.4883203506, 2.9859845638, 3.5831816196]
+    assert np.allclose(t["scale"][:8], want, rtol=0, atol=5e-10 * 4)
+    assert [int(31 * s) for s in t["scale"]] == [31, 37, 44, 53, 64, 77, 92, 111, 133, 159, 191, 230]
+    assert np.array_equal(t["inv_scale"], (np.float32(1.0) / t["scale"]).astype(np.float32))
+    assert np.array_equal(t["sigma2"], t["scale"] * t["scale"])
+
+
+def test_level_sizes(oracle, vsa):
+    table = {
+        (640, 480, 8): [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)],
+        (752, 480, 8): [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)],
+        (1241, 376, 8): [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)],
+    }
+    for (w, h, nl), want in table.items():
+        ex = oracle.Extractor(oracle.make_params(1000, 1.2, nl))
+        ex.extract(np.zeros((h, w), np.uint8))
+        assert [ex.level_size(l) for l in range(nl)] == want
+        assert sum(a * b for a, b in want) in (950532, 1117367, 1444097)
+
+
+def test_cv_round_and_atan2(oracle):
+    assert [oracle.cv_round(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+    assert oracle.fast_atan2(0, 0) == 0.0
+    for y, x, deg in ((0, 1, 0), (1, 0, 90), (0, -1, 180), (-1, 0, 270), (1, 1, 45), (-1, -1, 225)):
+        assert abs(oracle.fast_atan2(y, x) - deg) < 0.02
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        y, x = rng.integers(-2 ** 20, 2 ** 20, 2)
+        a = oracle.fast_atan2(float(y), float(x))
+        assert 0 <= a <= 360
+        assert abs((a - np.degrees(np.arctan2(y, x))) % 360) < 0.02 or abs((a - np.degrees(np.arctan2(y, x))) % 360) > 359.98
+
+
+def test_gauss_taps_and_blur(oracle):
+    assert oracle.gauss_taps().tolist() == [18, 34, 49, 55, 49, 34, 18]
+    const = np.full((20, 24), 77, np.uint8)
+    # taps sum to 257 (not renormalised): 77*257*257 = 5085773; (x + 32768) >> 16 = 78
+    assert (oracle.gauss7(const) == 78).all()
+    assert (oracle.gauss7(np.full((9, 9), 255, np.uint8)) == 255).all()      # saturates
+    imp = np.zeros((15, 15), np.uint8); imp[7, 7] = 255
+    out = oracle.gauss7(imp)
+    taps = np.array([18, 34, 49, 55, 49, 34, 18])
+    want = (np.outer(taps, taps) * 255 + 32768) >> 16
+    assert np.array_equal(out[4:11, 4:11], want)
+    assert out.sum() == want.sum()
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (41, 53), dtype=np.uint8)
+    a, b = oracle.gauss7(img, 0), oracle.gauss7(img, 1)
+    # the two rounding modes differ only on exact .5 ties and never in the last w%4 columns
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    assert np.array_equal(a[:, 52:], b[:, 52:])
+    pad = np.pad(img, 3, mode="reflect").astype(np.int64)
+    rows = sum(taps[k] * pad[3:-3, k:k + 53] for k in range(7))
+    rows = np.pad(rows, ((3, 3), (0, 0)), mode="reflect")
+    full = sum(taps[k] * rows[k:k + 41, :] for k in range(7))
+    assert np.array_equal(a, np.minimum((full + 32768) >> 16, 255).astype(np.uint8))
+
+
+def test_border101(oracle):
+    img = np.arange(5 * 7, dtype=np.uint8).reshape(5, 7)
+    assert np.array_equal(oracle.border101(img, 3), np.pad(img, 3, mode="reflect"))
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (40, 64), dtype=np.uint8)
+    assert np.array_equal(oracle.border101(img, 19), np.pad(img, 19, mode="reflect"))
+
+
+def test_resize_properties(oracle):
+    const = np.full((48, 64), 201, np.uint8)
+    assert (oracle.resize_linear(const, 53, 40) == 201).all()
+    # exact 2x decimation is rerouted to INTER_AREA: rounded 2x2 mean
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (40, 60), dtype=np.uint8)
+    a = img.astype(int)
+    want = (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(oracle.resize_linear(img, 30, 20), want.astype(np.uint8))
+    # horizontal ramp stays monotone and inside the source range
+    ramp = np.tile(np.arange(0, 240, 2, dtype=np.uint8), (30, 1))
+    out = oracle.resize_linear(ramp, 100, 25)
+    assert (np.diff(out.astype(int), axis=1) >= 0).all() and out.min() >= 0 and out.max() <= 238
+    # independent restatement of the fixed-point formula in numpy for one random case
+    src = rng.integers(0, 256, (37, 45), dtype=np.uint8)
+    dw, dh = 38, 31
+    sx_scale, sy_scale = 1.0 / (dw / 45), 1.0 / (dh / 37)
+    out = oracle.resize_linear(src, dw, dh)
+    ref = np.zeros((dh, dw), np.uint8)
+    for dy in range(dh):
+        fy = np.float32((dy + 0.5) * sy_scale - 0.5); sy = int(np.floor(fy)); fy = np.float32(fy - np.float32(sy))
+        b0 = int(np.rint(np.float32(np.float32(1) - fy) * np.float32(2048))); b1 = int(np.rint(fy * np.float32(2048)))
+        r0, r1 = min(max(sy, 0), 36), min(max(sy + 1, 0), 36)
+        for dx in range(dw):
+            fx = np.float32((dx + 0.5) * sx_scale - 0.5); sx = int(np.floor(fx)); fx = np.float32(fx - np.float32(sx))
+            if sx >= 44:
+                sx, fx = 44, np.float32(0)
+            a0 = int(np.rint(np.float32(np.float32(1) - fx) * np.float32(2048))); a1 = int(np.rint(fx * np.float32(2048)))
+            sx1 = min(sx + 1, 44)
+            h0 = int(src[r0, sx]) * a0 + int(src[r0, sx1]) * a1
+            h1 = int(src[r1, sx]) * a0 + int(src[r1, sx1]) * a1
+            ref[dy, dx] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
+    assert np.array_equal(out, ref)
+
+
+def test_fast_hand_cases(oracle):
+    # constant image: no corner at any threshold
+    assert len(oracle.fast9(np.full((40, 40), 90, np.uint8), 7)[0]) == 0
+    # filled quadrant: 11 contiguous ring pixels are darker by 100 -> score 99, a corner for every T < 100
+    img = np.zeros((31, 31), np.uint8); img[15:, 15:] = 100
+    assert oracle.fast9_score(img, 15, 15, 20) == 99
+    x, y, s = oracle.fast9(img, 20, nonmax=False)
+    assert (15, 15) in set(zip(x.tolist(), y.tolist()))
+    assert len(oracle.fast9(img, 100, nonmax=False)[0]) == 0
+    # (16,16) scores 99 as well: equal neighbours suppress each other, so NMS leaves neither
+    assert oracle.fast9_score(img, 16, 16, 20) == 99
+    x, y, s = oracle.fast9(img, 20, nonmax=True)
+    assert (15, 15) not in set(zip(x.tolist(), y.tolist()))
+    # an isolated bright pixel: all 16 ring pixels darker by 255 -> one keypoint, score 254
+    dot = np.zeros((21, 21), np.uint8); dot[10, 10] = 255
+    x, y, s = oracle.fast9(dot, 20)
+    assert (x.tolist(), y.tolist(), s.tolist()) == ([10], [10], [254])
+    # a straight edge is not a corner (8 contiguous at most on the far side)
+    edge = np.zeros((31, 31), np.uint8); edge[:, 15:] = 200
+    assert len(oracle.fast9(edge, 20)[0]) == 0
+    # score does not depend on the detection threshold; corner at T <=> score >= T
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (60, 60), dtype=np.uint8)
+    x7, y7, s7 = oracle.fast9(img, 7, nonmax=False)
+    x20, y20, s20 = oracle.fast9(img, 20, nonmax=False)
+    assert len(x7) > len(x20) > 0
+    pts7 = set(zip(x7.tolist(), y7.tolist())); pts20 = set(zip(x20.tolist(), y20.tolist()))
+    assert pts20 <= pts7
+    for xx, yy in list(pts7)[:200]:
+        sc = oracle.fast9_score(img, xx, yy, 7)
+        assert sc >= 7 and ((xx, yy) in pts20) == (sc >= 20)
+        assert oracle.fast9_score(img, xx, yy, 0) == sc
+    # detection range excludes the 3-pixel ring of the sub-image
+    assert x7.min() >= 3 and y7.min() >= 3 and x7.max() <= 56 and y7.max() <= 56
+
+
+def test_descriptor_distance(oracle, vsa):
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, 32, dtype=np.uint8)
+    b = rng.integers(0, 256, 32, dtype=np.uint8)
+    assert oracle.descriptor_distance(a, a) == 0
+    assert oracle.descriptor_distance(a, ~a) == 256
+    assert oracle.descriptor_distance(a, b) == oracle.descriptor_distance(b, a) == int(np.unpackbits(a ^ b).sum())
+    assert vsa.descriptor_distance(a, b) == oracle.descriptor_distance(a, b)
+
+
+def test_three_maxima_and_rotation_bins(oracle, vsa):
+    for impl in (oracle, vsa):
+        assert impl.compute_three_maxima([10] + [0] * 29) == (0, -1, -1)
+        assert impl.compute_three_maxima([10, 1, 1] + [0] * 27) == (0, 1, 2)
+        assert impl.compute_three_maxima([100, 9, 9] + [0] * 27) == (0, -1, -1)
+        assert impl.compute_three_maxima([100, 10, 9] + [0] * 27) == (0, 1, -1)
+        assert impl.compute_three_maxima([0] * 30) == (-1, -1, -1)
+        assert impl.compute_three_maxima([1, 2, 3, 4] + [0] * 26) == (3, 2, 1)
+    # factor = 1/HISTO_LENGTH: rot = 359 deg lands in bin round(359/30) = 12
+    assert round(359 * (1.0 / 30)) == 12
+
+
+def test_distribute_octree_properties(oracle):
+    rng = np.random.default_rng(6)
+    for it in range(30):
+        W, H = int(rng.integers(100, 900)), int(rng.integers(100, 500))
+        if round(W / H) < 1:
+            continue
+        n = int(rng.integers(1, 3000))
+        pts = sorted({(int(rng.integers(3, H - 3)), int(rng.integers(3, W - 3))) for _ in range(n)})
+        y = np.array([p[0] for p in pts], np.int16); x = np.array([p[1] for p in pts], np.int16)
+        s = rng.integers(7, 255, len(pts)).astype(np.uint8)
+        N = int(rng.integers(1, 300))
+        sel = oracle.distribute_octree(x, y, s, 16, 16 + W, 16, 16 + H, N)
+        assert len(set(sel.tolist())) == len(sel)
+        assert len(sel) <= max(N + 3, 4 * round(W / H))
+        if len(pts) <= N:
+            assert len(sel) == len(pts)          # splitting stopped because every node holds one key
+    assert len(oracle.distribute_octree(np.zeros(0, np.int16), np.zeros(0, np.int16), np.zeros(0, np.uint8), 16, 616, 16, 464, 100)) == 0
+
+
+def test_extract_is_deterministic_and_bounded(oracle, vsa):
+    img = vsa.synth_frame(0, 640, 480)
+    ex = oracle.Extractor(oracle.make_params())
+    k1, d1 = ex.extract(img)
+    k2, d2 = ex.extract(img)
+    assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
+    assert 900 <= len(k1) <= 1000 + 3 * 8
+    assert (k1["octave"][:-1] <= k1["octave"][1:]).all()
+    assert k1["class_id"].tolist() == [-1] * len(k1)
+    lvl0 = k1[k1["octave"] == 0]
+    assert lvl0["x"].min() >= 19 and lvl0["x"].max() <= 640 - 20 and lvl0["y"].min() >= 19 and lvl0["y"].max() <= 480 - 20
+    assert (k1["angle"] >= 0).all() and (k1["angle"] <= 360).all()
+    kc, dc = ex.extract(np.full((480, 640), 128, np.uint8))
+    assert len(kc) == 0

@@ -74,6 +74,7 @@ _SIGS = {
     "orbx_hamming_best2": (_i, [_vp, _vp, _i, _vp, _i64, _vp]),
     "orbx_hamming_best2_device": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _vp, _vp]),
     "orbx_best2_merge_device": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "orbx_best2_merge": (_i, [_vp, _i, _i, _vp]),
     "orbx_hamming_best2_workspace_bytes": (_i64, [_i, _i64]),
     "orbx_hamming_csr": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "orbx_grid_create": (_i, [_vp, _i, _f, _f, _f, _f, C.POINTER(_vp)]),
@@ -170,6 +171,14 @@ def compute_three_maxima(sizes):
     i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
     lib.orbx_compute_three_maxima(_ptr(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
     return i1.value, i2.value, i3.value
+
+
+def best2_merge(parts):
+    """parts: [n_parts, nq] BEST2_DTYPE (best_idx global) -> [nq]"""
+    parts = np.ascontiguousarray(parts, BEST2_DTYPE)
+    out = np.zeros(parts.shape[1], BEST2_DTYPE)
+    _check(lib.orbx_best2_merge(_ptr(parts), parts.shape[0], parts.shape[1], _ptr(out)))
+    return out
 
 
 def unpack_keys(packed):

@@ -376,6 +376,25 @@ void orbx_compute_three_maxima(const int32_t* sizes, int L, int* ind1, int* ind2
     else if (m3 < 0.1f * (float)m1) { *ind3 = -1; }
 }
 
+// Merge of per-shard best/second records: lowest distance, then lowest global index; the second is
+// the second smallest of the union, which is what one sequential pass over the whole set yields.
+int orbx_best2_merge(const orbx_best2* parts, int n_parts, int nq, orbx_best2* out)
+{
+    if (!parts || !out || n_parts < 1 || nq < 0) return ORBX_ERR_BAD_ARG;
+    for (int qi = 0; qi < nq; ++qi) {
+        int best = 256, second = 256, idx = -1;
+        for (int p = 0; p < n_parts; ++p) {
+            const orbx_best2& r = parts[(size_t)p * nq + qi];
+            if (r.best_idx < 0) continue;
+            if (r.best < best || (r.best == best && r.best_idx < idx)) { second = std::min(second, best); best = r.best; idx = r.best_idx; }
+            else second = std::min(second, r.best);
+            second = std::min(second, r.second);
+        }
+        out[qi].best = best; out[qi].best_idx = idx; out[qi].second = second; out[qi].pad = 0;
+    }
+    return ORBX_OK;
+}
+
 struct orbx_frame_grid { FrameGrid g; };
 
 int orbx_grid_create(const orbx_keypoint* kps, int n, float minX, float maxX, float minY, float maxY, orbx_frame_grid** out)
