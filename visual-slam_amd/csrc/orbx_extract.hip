@@ -41,15 +41,19 @@ struct DevLevel {
     int area2x, rx_offset, ry_offset;
     float scale, kp_size;
     int key_offset;   // offset of this level's compact key array inside one frame's key scratch
+    int fast_resize;  // every aligned group of 4 destination columns reads <= 8 consecutive source bytes
+    int rg_offset;    // first ResizeGroup record of this level
+    int cpr;          // 16-byte chunks per ROI row, ceil(w/16)
+    unsigned cpr_magic; // ceil(2^32 / cpr): row of flat chunk index i is umulhi(i, cpr_magic)
+    int border_threads; // threads of k_borders for this level
     int pad;
 };
 
 __device__ __constant__ signed char c_pattern[1024] = {
 #include "../../include/orbx_pattern.inc"
 };
-// circular patch row ends (src/ORBextractor.cc:453-468); constant for HALF_PATCH_SIZE = 15
-__device__ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
+typedef unsigned short us16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return *reinterpret_cast<const u32_unaligned*>(p); }
 
@@ -65,66 +69,146 @@ __device__ __forceinline__ int reflect101(int p, int len)
 // Level 0: copy the input into the padded pyramid buffer and write the REFLECT_101 frame.
 // One thread writes one aligned dword of a padded row.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Pyramid.  Interior pixels are produced 16 per thread in flat (row-major) order, so a wavefront writes
+// 1 KiB of consecutive bytes; the REFLECT_101 frames of all levels are filled by one separate launch
+// (a frame pixel is a copy of the interior pixel it mirrors), which keeps the interior kernels free of
+// divergent border code.
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(1))) u128_unaligned { uint32_t x, y, z, w; };
+
+// flat chunk index -> (row, chunk in row) with a precomputed reciprocal (exact for the index range used)
+__device__ __forceinline__ void split_index(uint32_t i, uint32_t cpr, uint32_t magic, uint32_t& row, uint32_t& col)
+{
+    row = __umulhi(i, magic);
+    col = i - row * cpr;
+}
+
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img, long long row_stride, long long frame_stride,
                                                 uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L)
 {
-    const int c = 4 * (blockIdx.x * 256 + threadIdx.x);
-    if (c >= L.stride) return;
-    const int py = blockIdx.y - kEdge;
-    const int sy = reflect101(py, L.h);
-    const uint8_t* srow = img + (long long)blockIdx.z * frame_stride + (long long)sy * row_stride;
-    uint8_t* drow = pyr + (unsigned long long)blockIdx.z * pyr_bytes + L.offset + (unsigned long long)blockIdx.y * L.stride;
-    const int x = c - kRoiX;
-    uint32_t v;
-    if (x >= 0 && x + 3 < L.w) {
-        v = load_u32(srow + x);
-    } else {
-        v = 0;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (uint32_t)(L.cpr * L.h)) return;
+    uint32_t y, ch;
+    split_index(i, L.cpr, L.cpr_magic, y, ch);
+    const uint8_t* s = img + (long long)blockIdx.y * frame_stride + (long long)y * row_stride + 16 * ch;
+    uint4 v;
+    if ((int)(16 * ch + 16) <= L.w) {
+        const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(s);
+        v = make_uint4(t.x, t.y, t.z, t.w);
+    } else {                                   // last chunk of a row: do not read past the source row
+        uint32_t t[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int xx = x + k;
-            uint32_t b = 0;
-            if (xx >= -kEdge && xx < L.w + kEdge) b = srow[reflect101(xx, L.w)];
-            v |= b << (8 * k);
-        }
+        for (int k = 0; k < 16; ++k) if ((int)(16 * ch) + k < L.w) t[k >> 2] |= (uint32_t)s[k] << (8 * (k & 3));
+        v = make_uint4(t[0], t[1], t[2], t[3]);
     }
-    *reinterpret_cast<uint32_t*>(drow + c) = v;
+    *reinterpret_cast<uint4*>(pyr + (unsigned long long)blockIdx.y * pyr_bytes + L.roi + (unsigned long long)y * L.stride + 16 * ch) = v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Level l from level l-1: cv::resize INTER_LINEAR for 8-bit (Q11 weights, two-stage rounding) and
-// the REFLECT_101 frame in the same pass (a frame pixel is the interior pixel it mirrors).
-// ---------------------------------------------------------------------------------------------
+// Level l from level l-1: cv::resize INTER_LINEAR for 8-bit (Q11 weights, two-stage rounding).
+// Four adjacent destination columns read at most 8 consecutive source bytes per row; one v_perm_b32
+// pulls a column's two neighbours out of that window as 16-bit lanes, one v_dot2_u32_u16 applies the weights.
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel S, DevLevel D,
-                                                const ResizeX* __restrict__ rxt, const ResizeY* __restrict__ ryt)
+                                                const ResizeY* __restrict__ ryt, const ResizeGroup* __restrict__ rgt)
 {
-    const int c = 4 * (blockIdx.x * 256 + threadIdx.x);
-    if (c >= D.stride) return;
-    uint8_t* base = pyr + (unsigned long long)blockIdx.z * pyr_bytes;
-    const uint8_t* sroi = base + S.roi;
-    const int y = reflect101((int)blockIdx.y - kEdge, D.h);
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (uint32_t)(D.cpr * D.h)) return;
+    uint32_t y, ch;
+    split_index(i, D.cpr, D.cpr_magic, y, ch);
+    uint8_t* base = pyr + (unsigned long long)blockIdx.y * pyr_bytes;
     const ResizeY ey = ryt[D.ry_offset + y];
-    const uint8_t* s0 = sroi + (long long)ey.sy0 * S.stride;
-    const uint8_t* s1 = sroi + (long long)ey.sy1 * S.stride;
+    const uint8_t* s0 = base + S.roi + (long long)ey.sy0 * S.stride;
+    const uint8_t* s1 = base + S.roi + (long long)ey.sy1 * S.stride;
+    const uint32_t b0 = (uint32_t)(int)ey.b0, b1 = (uint32_t)(int)ey.b1;
+    const uint4* tp = reinterpret_cast<const uint4*>(rgt + (size_t)(D.rg_offset + 4 * ch));
+    uint32_t out[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint4 ta = tp[2 * g], tb = tp[2 * g + 1];     // {sx_first, 4 byte offsets, w0, w1} {w2, w3, -, -}
+        const int sx0 = (int)ta.x;
+        const uint32_t wt[4] = {ta.z, ta.w, tb.x, tb.y};
+        const uint32_t lo0 = load_u32(s0 + sx0), hi0 = load_u32(s0 + sx0 + 4);
+        const uint32_t lo1 = load_u32(s1 + sx0), hi1 = load_u32(s1 + sx0 + 4);
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t sel = ((ta.y >> (8 * k)) & 0xFFu) * 0x00010001u + 0x0c010c00u;   // bytes off, off+1 -> lanes 0, 1
+            const us16x2 w = __builtin_bit_cast(us16x2, wt[k]);
+            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(hi0, lo0, sel)), w, 0u, false);
+            const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(hi1, lo1, sel)), w, 0u, false);
+            const uint32_t b = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2u) >> 2) & 0xFFu;
+            v |= b << (8 * k);
+        }
+        out[g] = v;
+    }
+    *reinterpret_cast<uint4*>(base + D.roi + (unsigned long long)y * D.stride + 16 * ch) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// Generic form (per-pixel table, exact 2x decimation rerouted to the 2x2 mean as OpenCV does): used for
+// levels whose geometry does not fit the 8-byte window of the fast kernel.
+__global__ __launch_bounds__(256) void k_resize_generic(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel S, DevLevel D,
+                                                        const ResizeX* __restrict__ rxt, const ResizeY* __restrict__ ryt)
+{
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= D.w || y >= D.h) return;
+    uint8_t* base = pyr + (unsigned long long)blockIdx.z * pyr_bytes;
+    const ResizeY ey = ryt[D.ry_offset + y];
+    const uint8_t* s0 = base + S.roi + (long long)ey.sy0 * S.stride;
+    const uint8_t* s1 = base + S.roi + (long long)ey.sy1 * S.stride;
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int xx = c + k - kRoiX;
-        uint32_t b = 0;
-        if (xx >= -kEdge && xx < D.w + kEdge) {
-            const ResizeX ex = rxt[D.rx_offset + reflect101(xx, D.w)];
-            const int p00 = s0[ex.sx], p01 = s0[ex.sx + 1], p10 = s1[ex.sx], p11 = s1[ex.sx + 1];
-            if (D.area2x) {
-                b = (uint32_t)((p00 + p01 + p10 + p11 + 2) >> 2);
-            } else {
-                const int h0 = p00 * ex.a0 + p01 * ex.a1;
-                const int h1 = p10 * ex.a0 + p11 * ex.a1;
-                b = (uint32_t)((((ey.b0 * (h0 >> 4)) >> 16) + ((ey.b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;
-            }
+        const int xx = min(x0 + k, D.w - 1);
+        const ResizeX ex = rxt[D.rx_offset + xx];
+        const int p00 = s0[ex.sx], p01 = s0[ex.sx + 1], p10 = s1[ex.sx], p11 = s1[ex.sx + 1];
+        uint32_t b;
+        if (D.area2x) {
+            b = (uint32_t)((p00 + p01 + p10 + p11 + 2) >> 2);
+        } else {
+            const int h0 = p00 * ex.a0 + p01 * ex.a1;
+            const int h1 = p10 * ex.a0 + p11 * ex.a1;
+            b = (uint32_t)((((ey.b0 * (h0 >> 4)) >> 16) + ((ey.b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;
         }
         v |= b << (8 * k);
     }
-    *reinterpret_cast<uint32_t*>(base + D.offset + (unsigned long long)blockIdx.y * D.stride + c) = v;
+    *reinterpret_cast<uint32_t*>(base + D.roi + (unsigned long long)y * D.stride + x0) = v;
+}
+
+// REFLECT_101 frames of every level (cv::copyMakeBorder, src/ORBextractor.cc:1121-1127).  One thread per
+// dword of the frame area: all dwords of the 19 top and 19 bottom rows, and in the rows between them the
+// dwords left of the ROI (8) and from its right end to the end of the padded row.
+__global__ __launch_bounds__(256) void k_borders(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, const DevLevel* __restrict__ lv)
+{
+    const DevLevel& L = lv[blockIdx.y];
+    const int dpr = L.stride >> 2;                       // dwords per padded row
+    const int rfirst = (kRoiX + L.w) >> 2;               // first dword touching the right frame
+    const int side = 8 + (dpr - rfirst);                 // frame dwords of a middle row
+    const int nfull = 2 * kEdge * dpr;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nfull + L.h * side) return;
+    int prow, d;
+    if (i < nfull) {
+        const int r = i / dpr;
+        d = i - r * dpr;
+        prow = r < kEdge ? r : L.h + r;                  // rows 0..18 and h+19..h+37
+    } else {
+        const int j = i - nfull;
+        const int r = j / side, k = j - r * side;
+        prow = kEdge + r;
+        d = k < 8 ? k : rfirst + (k - 8);
+    }
+    uint8_t* base = pyr + (unsigned long long)blockIdx.z * pyr_bytes;
+    const uint8_t* srow = base + L.roi + (long long)reflect101(prow - kEdge, L.h) * L.stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xx = 4 * d + k - kRoiX;
+        uint32_t b = 0;
+        if (xx >= -kEdge && xx < L.w + kEdge) b = srow[reflect101(xx, L.w)];
+        v |= b << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(base + L.offset + (unsigned long long)prow * L.stride + 4 * d) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -180,6 +264,45 @@ __device__ __forceinline__ int fast_score(const uint8_t* t)
     return max(dark, -bright) - 1;
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t u) { return __builtin_bit_cast(s16x2, u); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+
+// bytes POS and POS+1 of the 12-byte window {w0,w1,w2}, zero-extended into two 16-bit lanes
+template <int POS>
+__device__ __forceinline__ s16x2 pair16(uint32_t w0, uint32_t w1, uint32_t w2)
+{
+    if constexpr (POS + 1 <= 7)
+        return as_s16x2(__builtin_amdgcn_perm(w1, w0, 0x0c000c00u | (uint32_t)POS | ((uint32_t)(POS + 1) << 16)));
+    else
+        return as_s16x2(__builtin_amdgcn_perm(w2, w1, 0x0c000c00u | (uint32_t)(POS - 4) | ((uint32_t)(POS - 3) << 16)));
+}
+
+// Necessary condition for two horizontally adjacent pixels at once (16-bit packed lanes): an arc of 9
+// ring pixels holds one pixel of every antipodal pair, so a corner needs, for each of the four
+// even pairs (0,8) (2,10) (4,12) (6,14), one member darker than v-t -- or, for a bright corner, brighter
+// than v+t.  Returns max(min_k max(d_k,d_k+8), -max_k min(d_k,d_k+8)) per lane; a corner needs > t.
+template <int J0>
+__device__ __forceinline__ uint32_t fast_pretest(const uint32_t (&m3)[3], const uint32_t (&m2)[3], const uint32_t (&c)[3],
+                                                 const uint32_t (&p2)[3], const uint32_t (&p3)[3])
+{
+    const s16x2 v = pair16<3 + J0>(c[0], c[1], c[2]);
+    const s16x2 d0 = v - pair16<3 + J0>(p3[0], p3[1], p3[2]);    // ( 0,+3)
+    const s16x2 d8 = v - pair16<3 + J0>(m3[0], m3[1], m3[2]);    // ( 0,-3)
+    const s16x2 d4 = v - pair16<6 + J0>(c[0], c[1], c[2]);       // (+3, 0)
+    const s16x2 d12 = v - pair16<0 + J0>(c[0], c[1], c[2]);      // (-3, 0)
+    const s16x2 d2 = v - pair16<5 + J0>(p2[0], p2[1], p2[2]);    // (+2,+2)
+    const s16x2 d14 = v - pair16<1 + J0>(p2[0], p2[1], p2[2]);   // (-2,+2)
+    const s16x2 d6 = v - pair16<5 + J0>(m2[0], m2[1], m2[2]);    // (+2,-2)
+    const s16x2 d10 = v - pair16<1 + J0>(m2[0], m2[1], m2[2]);   // (-2,-2)
+    const s16x2 dark = pmin(pmin(pmax(d0, d8), pmax(d4, d12)), pmin(pmax(d2, d10), pmax(d6, d14)));
+    const s16x2 bright = pmax(pmax(pmin(d0, d8), pmin(d4, d12)), pmax(pmin(d2, d10), pmin(d6, d14)));
+    const s16x2 zero = {0, 0};
+    return as_u32(pmax(dark, zero - bright));
+}
+
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
                                                     const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
                                                     uint32_t* __restrict__ cand, int cand_total,
@@ -188,12 +311,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     __shared__ __align__(16) uint8_t tile[kTileRows * kTileStride];
     __shared__ __align__(16) uint8_t score[(kMaxCellDim + 2) * kScoreStride];
     __shared__ uint16_t queue[kMaxCellDim * kMaxCellDim];
+    __shared__ unsigned long long rowIni[64], rowMin[64];
     __shared__ int qn;
-    __shared__ int wcount[4];
-    __shared__ int anyIni;
-    __shared__ int outBase;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const CellRec c = cells[blockIdx.x];
     const DevLevel& L = lv[c.level];
     const uint8_t* src = pyr + (unsigned long long)blockIdx.y * pyr_bytes + L.roi + (long long)c.y0 * L.stride + c.x0;
@@ -205,22 +326,36 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         *reinterpret_cast<uint32_t*>(&tile[r * kTileStride + 4 * d]) = load_u32(src + (long long)r * L.stride + 4 * d);
     }
     for (int i = tid; i < (ch + 2) * (kScoreStride / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
-    if (tid == 0) { qn = 0; anyIni = 0; outBase = 0; }
+    if (tid < 64) { rowIni[tid] = 0; rowMin[tid] = 0; }
+    if (tid == 0) qn = 0;
     __syncthreads();
 
     const int lowTh = min(iniTh, minTh);
-    const int npix = cw * ch;
-    // pass 1: a 9-arc always holds two adjacent compass points (0,4,8,12): cheap necessary test
-    for (int i = tid; i < npix; i += 256) {
-        const int y = i / cw, x = i - y * cw;
-        const uint8_t* t = &tile[(y + 3) * kTileStride + x + 3];
-        const int v = t[0];
-        const int d0 = v - t[3 * kTileStride], d4 = v - t[3], d8 = v - t[-3 * kTileStride], d12 = v - t[-3];
-        const int dk = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
-        const int br = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
-        if (dk > lowTh || br < -lowTh) {
-            const int slot = atomicAdd(&qn, 1);
-            queue[slot] = (uint16_t)i;
+    // pass 1: four pixels per thread, cheap necessary test on packed pairs; survivors are queued
+    const int gpr = (cw + 3) >> 2;
+    for (int gi = tid; gi < gpr * ch; gi += 256) {
+        const int y = gi / gpr, g = gi - y * gpr;
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(&tile[y * kTileStride]) + g;   // tile row y = image row y-3
+        constexpr int RS = kTileStride / 4;
+        const uint32_t m3[3] = {row[0], row[1], row[2]};
+        const uint32_t m2[3] = {row[RS], row[RS + 1], row[RS + 2]};
+        const uint32_t cc[3] = {row[3 * RS], row[3 * RS + 1], row[3 * RS + 2]};
+        const uint32_t p2[3] = {row[5 * RS], row[5 * RS + 1], row[5 * RS + 2]};
+        const uint32_t p3[3] = {row[6 * RS], row[6 * RS + 1], row[6 * RS + 2]};
+        const uint32_t t01 = fast_pretest<0>(m3, m2, cc, p2, p3);
+        const uint32_t t23 = fast_pretest<2>(m3, m2, cc, p2, p3);
+        const int x = 4 * g;
+        const bool pass[4] = {(int)(short)(t01 & 0xFFFFu) > lowTh && x < cw, ((int)t01 >> 16) > lowTh && x + 1 < cw,
+                              (int)(short)(t23 & 0xFFFFu) > lowTh && x + 2 < cw, ((int)t23 >> 16) > lowTh && x + 3 < cw};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long m = __ballot(pass[j]);
+            if (m) {
+                int base = 0;
+                if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&qn, __popcll(m));
+                base = __shfl(base, __ffsll((long long)m) - 1, 64);
+                if (pass[j]) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y * 64 + x + j);
+            }
         }
     }
     __syncthreads();
@@ -228,59 +363,48 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const int nq = qn;
     for (int e = tid; e < nq; e += 256) {
         const int i = queue[e];
-        const int y = i / cw, x = i - y * cw;
+        const int y = i >> 6, x = i & 63;
         const int s = fast_score(&tile[(y + 3) * kTileStride + x + 3]);
         if (s >= lowTh && s >= 1) score[(y + 1) * kScoreStride + x + 1] = (uint8_t)s;
     }
     __syncthreads();
-    // pass 3: strict local maxima inside the cell; does any reach the initial threshold?
-    const int iters = (npix + 255) >> 8;
-    uint32_t keptMask = 0;
-    bool ini = false;
-    for (int it = 0; it < iters; ++it) {
-        const int i = it * 256 + tid;
-        if (i < npix) {
-            const int y = i / cw, x = i - y * cw;
-            const uint8_t* sp = &score[(y + 1) * kScoreStride + x + 1];
-            const int s = sp[0];
-            if (s > 0) {
-                const bool mx = s > sp[-1] && s > sp[1] &&
-                                s > sp[-kScoreStride - 1] && s > sp[-kScoreStride] && s > sp[-kScoreStride + 1] &&
-                                s > sp[kScoreStride - 1] && s > sp[kScoreStride] && s > sp[kScoreStride + 1];
-                if (mx) { keptMask |= 1u << it; ini |= (s >= iniTh); }
+    // pass 3: strict local maxima inside the cell, recorded as one 64-bit mask per row
+    const int tIni = max(iniTh, 1), tMin = max(minTh, 1);
+    for (int e = tid; e < nq; e += 256) {
+        const int i = queue[e];
+        const int y = i >> 6, x = i & 63;
+        const uint8_t* sp = &score[(y + 1) * kScoreStride + x + 1];
+        const int s = sp[0];
+        if (s > 0) {
+            const bool mx = s > sp[-1] && s > sp[1] &&
+                            s > sp[-kScoreStride - 1] && s > sp[-kScoreStride] && s > sp[-kScoreStride + 1] &&
+                            s > sp[kScoreStride - 1] && s > sp[kScoreStride] && s > sp[kScoreStride + 1];
+            if (mx) {
+                if (s >= tMin) atomicOr(&rowMin[y], 1ull << x);
+                if (s >= tIni) atomicOr(&rowIni[y], 1ull << x);
             }
         }
     }
-    if (__any(ini) && (tid & 63) == 0) anyIni = 1;
     __syncthreads();
-    const int T = max(anyIni ? iniTh : minTh, 1);
-    // pass 4: ordered (raster) compaction into this cell's slots
+    // pass 4 (first wavefront): lane r owns row r; raster-ordered emission into this cell's slots
+    if (tid >= 64) return;
+    const unsigned long long mi = lane < ch ? rowIni[lane] : 0ull;
+    const unsigned long long mm = lane < ch ? rowMin[lane] : 0ull;
+    unsigned long long mask = __any(mi != 0ull) ? mi : mm;
+    const int cnt = __popcll(mask);
+    int inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    const int total = __shfl(inc, 63, 64);
+    int pos = inc - cnt;
     uint32_t* out = cand + (unsigned long long)blockIdx.y * cand_total + L.cand_offset + c.slot;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int it = 0; it < iters; ++it) {
-        const int i = it * 256 + tid;
-        bool emit = false;
-        int x = 0, y = 0, s = 0;
-        if ((keptMask >> it) & 1u) {
-            y = i / cw; x = i - y * cw;
-            s = score[(y + 1) * kScoreStride + x + 1];
-            emit = s >= T;
-        }
-        const unsigned long long m = __ballot(emit);
-        if (lane == 0) wcount[wave] = __popcll(m);
-        __syncthreads();
-        int base = outBase;
-        for (int w = 0; w < wave; ++w) base += wcount[w];
-        if (emit) {
-            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < c.cap)
-                out[pos] = ((uint32_t)(x + 3 + c.offx) << 20) | ((uint32_t)(y + 3 + c.offy) << 8) | (uint32_t)s;
-        }
-        __syncthreads();
-        if (tid == 0) outBase += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-        __syncthreads();
+    while (mask) {
+        const int x = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int s = score[(lane + 1) * kScoreStride + x + 1];
+        if (pos < c.cap) out[pos] = ((uint32_t)(x + 3 + c.offx) << 20) | ((uint32_t)(lane + 3 + c.offy) << 8) | (uint32_t)s;
+        ++pos;
     }
-    if (tid == 0) cellcnt[(unsigned long long)blockIdx.y * ncells + blockIdx.x] = (uint16_t)min(outBase, c.cap);
+    if (lane == 0) cellcnt[(unsigned long long)blockIdx.y * ncells + blockIdx.x] = (uint16_t)min(total, c.cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -288,7 +412,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 // dense key array (cell-row-major, raster inside a cell: the reference's vToDistributeKeys order),
 // then runs the level-synchronous DistributeOctTree of octree_algo.h.
 // ---------------------------------------------------------------------------------------------
-constexpr int kOctThreads = 1024;
+constexpr int kOctThreads = 256;
 
 __device__ void ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads)
 {
@@ -372,7 +496,9 @@ __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* _
 // serves the intensity centroid (radius 15, unblurred), the separable 7x7 Gaussian restricted to the
 // 37x37 window the rotated pattern can reach, and the 256 binary tests.
 // ---------------------------------------------------------------------------------------------
-constexpr int kPatchW = 43, kPatchStride = 44, kBlurW = 37, kHStride = 38, kBlurStride = 40;
+constexpr int kPatchW = 43, kPatchStride = 44, kBlurW = 37, kBlurStride = 40;
+constexpr int kHRows = 44;      // rows per column of the transposed horizontal-pass buffer (43 used, even for dword pairs)
+constexpr int kHCols = 40;      // columns written by the horizontal pass (37 used)
 
 // LDS hand-off between the lanes of one wavefront: DS operations of a wave execute in issue order,
 // so only the compiler has to be kept from moving accesses across this point.
@@ -406,6 +532,57 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+// sin and cos of x in [0, 2*pi] in double precision (error ~1e-16), rounded to float by the caller: the
+// correctly rounded float value of cos/sin except when the true value lies within ~1e-16 (relative)
+// of a float rounding boundary.  Cody-Waite reduction by pi/2 and Taylor polynomials on [-pi/4, pi/4].
+__device__ __forceinline__ void sincos_0_2pi(double x, double& sn, double& cs)
+{
+    const double k = rint(x * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = -1.0 / 1307674368000.0;
+    ps = fma(ps, z, 1.0 / 6227020800.0);
+    ps = fma(ps, z, -1.0 / 39916800.0);
+    ps = fma(ps, z, 1.0 / 362880.0);
+    ps = fma(ps, z, -1.0 / 5040.0);
+    ps = fma(ps, z, 1.0 / 120.0);
+    ps = fma(ps, z, -1.0 / 6.0);
+    const double s = fma(r * z, ps, r);
+    double pc = 1.0 / 20922789888000.0;
+    pc = fma(pc, z, -1.0 / 87178291200.0);
+    pc = fma(pc, z, 1.0 / 479001600.0);
+    pc = fma(pc, z, -1.0 / 3628800.0);
+    pc = fma(pc, z, 1.0 / 40320.0);
+    pc = fma(pc, z, -1.0 / 720.0);
+    pc = fma(pc, z, 1.0 / 24.0);
+    pc = fma(pc, z, -0.5);
+    const double c = fma(pc, z, 1.0);
+    const int n = (int)k & 3;
+    sn = (n == 0) ? s : (n == 1) ? c : (n == 2) ? -s : -c;
+    cs = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
+}
+
+// Byte weights of the intensity-centroid sums for the nine aligned dwords (patch columns 4..39) of a
+// disc row |v|: wu = u + 15 inside the disc (u = column - 21), wm = 1 inside the disc, 0 outside.
+struct IcTable { uint32_t wu[16][9]; uint32_t wm[16][9]; };
+constexpr IcTable make_ic_table()
+{
+    constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    IcTable t{};
+    for (int v = 0; v < 16; ++v)
+        for (int i = 0; i < 9; ++i) {
+            uint32_t wu = 0, wm = 0;
+            for (int b = 0; b < 4; ++b) {
+                const int u = 4 + 4 * i + b - 21;
+                if (u >= -um[v] && u <= um[v]) { wu |= (uint32_t)(u + 15) << (8 * b); wm |= 1u << (8 * b); }
+            }
+            t.wu[v][i] = wu; t.wm[v][i] = wm;
+        }
+    return t;
+}
+__device__ __constant__ IcTable c_ic = make_ic_table();
+
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
                                                   const DevLevel* __restrict__ lv, int nlevels,
                                                   const uint32_t* __restrict__ lvlkp, int kp_total,
@@ -413,8 +590,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
                                                   orbx_keypoint* __restrict__ okp, uint8_t* __restrict__ odesc,
                                                   int32_t* __restrict__ ocount, int cap_per_frame, int blur_rounding)
 {
-    __shared__ __align__(16) uint8_t s_patch[4][kPatchW * kPatchStride];
-    __shared__ __align__(16) uint16_t s_h[4][kPatchW * kHStride];
+    __shared__ __align__(16) uint8_t s_patch[4][kPatchW * kPatchStride + 12];
+    __shared__ __align__(16) uint16_t s_h[4][kHCols * kHRows];
     __shared__ __align__(16) uint8_t s_blur[4][kBlurW * kBlurStride];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -437,59 +614,79 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     const int kx = (int)(key >> 20) + kMinBorder, ky = (int)((key >> 8) & 0xFFF) + kMinBorder;
     const int resp = (int)(key & 0xFF);
 
-    uint8_t* patch = s_patch[wave];
-    uint16_t* hbuf = s_h[wave];
+    uint32_t* patch = reinterpret_cast<uint32_t*>(s_patch[wave]);      // 11 dwords per row
+    uint16_t* hT = s_h[wave];
     uint8_t* blur = s_blur[wave];
     const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + L.roi + (long long)(ky - 21) * L.stride + (kx - 21);
     for (int i = lane; i < kPatchW * 11; i += 64) {
         const int r = i / 11, d = i - r * 11;
-        *reinterpret_cast<uint32_t*>(&patch[r * kPatchStride + 4 * d]) = load_u32(src + (long long)r * L.stride + 4 * d);
+        patch[i] = load_u32(src + (long long)r * L.stride + 4 * d);
     }
     wave_sync();
 
-    // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc
+    // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc, four pixels per
+    // v_dot4_u32_u8.  m10 = sum u*I = sum (u+15)*I - 15*sum I,  m01 = sum v*I.
     int m10 = 0, m01 = 0;
-    {
-        const int u = lane - kHalfPatch;
-        if (lane <= 2 * kHalfPatch) {
-            for (int v = -kHalfPatch; v <= kHalfPatch; ++v) {
-                const int av = v < 0 ? -v : v;
-                if (u >= -c_umax[av] && u <= c_umax[av]) {
-                    const int I = patch[(21 + v) * kPatchStride + 21 + u];
-                    m10 += u * I;
-                    m01 += v * I;
-                }
-            }
-        }
+    for (int i = lane; i < 31 * 9; i += 64) {
+        const int rr = i / 9, d = i - rr * 9;          // disc row rr-15, dword d+1 of the patch row
+        const int v = rr - kHalfPatch, av = v < 0 ? -v : v;
+        const uint32_t px = patch[(6 + rr) * 11 + 1 + d];
+        const uint32_t su = __builtin_amdgcn_udot4(px, c_ic.wu[av][d], 0u, false);
+        const uint32_t sm = __builtin_amdgcn_udot4(px, c_ic.wm[av][d], 0u, false);
+        m10 += (int)su - 15 * (int)sm;
+        m01 += v * (int)sm;
     }
     for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // GaussianBlur 7x7 sigma 2 (src/ORBextractor.cc:1085): Q8 taps 18,34,49,55,49,34,18
-    // rows of the window: patch rows 0..42 -> horizontal sums for columns 3..39 (window column j <-> patch column j+3)
-    for (int i = lane; i < kPatchW * kBlurW; i += 64) {
-        const int r = i / kBlurW, j = i - r * kBlurW;
-        const uint8_t* p = &patch[r * kPatchStride + j];
-        const int sum = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-        hbuf[r * kHStride + j] = (uint16_t)sum;
+    // GaussianBlur 7x7 sigma 2 (src/ORBextractor.cc:1085), Q8 taps 18,34,49,55,49,34,18, restricted to the
+    // 37x37 window the rotated pattern can reach.  Horizontal pass: window column j reads patch columns
+    // j..j+6; two v_dot4_u32_u8 per output; results stored transposed ([column][row], 16 bit).
+    constexpr uint32_t T0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), T1 = 49u | (34u << 8) | (18u << 16);
+    for (int i = lane; i < kPatchW * 10; i += 64) {
+        const int g = i / kPatchW, r = i - g * kPatchW;
+        const uint32_t w0 = patch[r * 11 + g], w1 = patch[r * 11 + g + 1], w2 = patch[r * 11 + g + 2];
+        uint16_t* o = hT + (4 * g) * kHRows + r;
+        o[0] = (uint16_t)__builtin_amdgcn_udot4(w1, T1, __builtin_amdgcn_udot4(w0, T0, 0u, false), false);
+        o[kHRows] = (uint16_t)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), T1,
+                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), T0, 0u, false), false);
+        o[2 * kHRows] = (uint16_t)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), T1,
+                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), T0, 0u, false), false);
+        o[3 * kHRows] = (uint16_t)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), T1,
+                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), T0, 0u, false), false);
     }
     wave_sync();
-    const int simdW = blur_rounding ? (L.w & ~3) : 0;
-    for (int i = lane; i < kBlurW * kBlurW; i += 64) {
-        const int r = i / kBlurW, j = i - r * kBlurW;
-        const uint16_t* p = &hbuf[r * kHStride + j];
-        const int sum = 18 * ((int)p[0] + p[6 * kHStride]) + 34 * ((int)p[kHStride] + p[5 * kHStride]) +
-                        49 * ((int)p[2 * kHStride] + p[4 * kHStride]) + 55 * (int)p[3 * kHStride];
-        const int imgx = kx - 18 + j;
-        int v = (imgx < simdW) ? ((sum + 32767 + ((sum >> 16) & 1)) >> 16) : ((sum + 32768) >> 16);
-        blur[r * kBlurStride + j] = (uint8_t)min(v, 255);
+    // Vertical pass: one lane produces window rows 2q and 2q+1 of one column from four aligned dwords
+    // (pairs of vertically adjacent 16-bit sums), four v_dot2_u32_u16 per output.
+    {
+        const uint32_t* hd = reinterpret_cast<const uint32_t*>(hT);
+        constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
+        constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
+        const int simdW = blur_rounding ? (L.w & ~3) : 0;
+        for (int i = lane; i < kBlurW * 19; i += 64) {
+            const int q = i / kBlurW, c = i - q * kBlurW;
+            const uint32_t* col = hd + c * (kHRows / 2) + q;
+            const us16x2 d0 = __builtin_bit_cast(us16x2, col[0]), d1 = __builtin_bit_cast(us16x2, col[1]);
+            const us16x2 d2 = __builtin_bit_cast(us16x2, col[2]), d3 = __builtin_bit_cast(us16x2, col[3]);
+#define ORBX_DOT2(a, w, acc) __builtin_amdgcn_udot2(a, __builtin_bit_cast(us16x2, (uint32_t)(w)), acc, false)
+            const uint32_t se = ORBX_DOT2(d3, E3, ORBX_DOT2(d2, E2, ORBX_DOT2(d1, E1, ORBX_DOT2(d0, E0, 0u))));
+            const uint32_t so = ORBX_DOT2(d3, O3, ORBX_DOT2(d2, O2, ORBX_DOT2(d1, O1, ORBX_DOT2(d0, O0, 0u))));
+#undef ORBX_DOT2
+            const bool even_ties = (kx - 18 + c) < simdW;
+            const uint32_t ve = even_ties ? ((se + 32767u + ((se >> 16) & 1u)) >> 16) : ((se + 32768u) >> 16);
+            const uint32_t vo = even_ties ? ((so + 32767u + ((so >> 16) & 1u)) >> 16) : ((so + 32768u) >> 16);
+            blur[(2 * q) * kBlurStride + c] = (uint8_t)min(ve, 255u);
+            if (2 * q + 1 < kBlurW) blur[(2 * q + 1) * kBlurStride + c] = (uint8_t)min(vo, 255u);
+        }
     }
     wave_sync();
 
     // computeOrbDescriptor (src/ORBextractor.cc:107-146)
     constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.0); // (float)(CV_PI/180.f)
     const float ang = __fmul_rn(angle, factorPI);
-    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    double sd, cd;
+    sincos_0_2pi((double)ang, sd, cd);
+    const float a = (float)cd, b = (float)sd;
     const size_t orow = (size_t)frame * cap_per_frame + outOff + idx;
     unsigned long long* dout = reinterpret_cast<unsigned long long*>(odesc + orow * 32);
 #pragma unroll
@@ -535,6 +732,7 @@ struct orbx_extractor {
     CellRec* d_cells = nullptr;
     ResizeX* d_rx = nullptr;
     ResizeY* d_ry = nullptr;
+    ResizeGroup* d_rg = nullptr;
     uint8_t* d_pyr = nullptr;
     uint32_t* d_cand = nullptr;
     uint16_t* d_cellcnt = nullptr;
@@ -548,6 +746,7 @@ struct orbx_extractor {
     uint8_t* d_odesc = nullptr;
     int32_t* d_ocount = nullptr;
     int key_total = 0;
+    int max_border_threads = 0;
     int NCmax = 0;
     size_t oct_lds = 0;
     int last_frames = 0;
@@ -591,6 +790,11 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         d.quota = g.quota; d.nIni = g.nIni; d.hX = g.hX; d.kp_offset = g.kp_offset; d.kp_cap = g.kp_cap;
         d.area2x = g.area2x; d.rx_offset = g.rx_offset; d.ry_offset = g.ry_offset; d.scale = g.scale; d.kp_size = g.kp_size;
         d.key_offset = key_off;
+        d.fast_resize = g.fast_resize;
+        d.rg_offset = g.rg_offset;
+        d.cpr = g.cpr; d.cpr_magic = g.cpr_magic;
+        d.border_threads = 2 * kEdge * (g.stride / 4) + g.h * (8 + g.stride / 4 - (kRoiX + g.w) / 4);
+        ex->max_border_threads = std::max(ex->max_border_threads, d.border_threads);
         key_off += (g.cand_cap + 3) & ~3;
         ncmax = std::max(ncmax, g.kp_cap);
         ex->hlv[l] = d;
@@ -610,6 +814,8 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK(hipMemcpy(ex->d_cells, geo.cells.data(), sizeof(CellRec) * geo.cells.size(), hipMemcpyHostToDevice));
     if (!geo.rx.empty()) HIP_CHECK(hipMemcpy(ex->d_rx, geo.rx.data(), sizeof(ResizeX) * geo.rx.size(), hipMemcpyHostToDevice));
     if (!geo.ry.empty()) HIP_CHECK(hipMemcpy(ex->d_ry, geo.ry.data(), sizeof(ResizeY) * geo.ry.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&ex->d_rg, sizeof(ResizeGroup) * std::max<size_t>(geo.rg.size(), 1)));
+    if (!geo.rg.empty()) HIP_CHECK(hipMemcpy(ex->d_rg, geo.rg.data(), sizeof(ResizeGroup) * geo.rg.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&ex->d_pyr, geo.pyr_bytes * B + 256));
     HIP_CHECK(hipMemset(ex->d_pyr, 0, geo.pyr_bytes * B + 256));
     HIP_CHECK(hipMalloc(&ex->d_cand, sizeof(uint32_t) * (size_t)geo.cand_total * B));
@@ -628,7 +834,7 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_rx, ex->d_ry, ex->d_pyr, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
+    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_rx, ex->d_ry, ex->d_rg, ex->d_pyr, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
                     ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : ex->ev) if (e) (void)hipEventDestroy(e);
@@ -651,15 +857,23 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[0], st));
     {
         const DevLevel& L0 = ex->hlv[0];
-        dim3 grid((L0.stride / 4 + 255) / 256, L0.rows, B);
+        dim3 grid((L0.cpr * L0.h + 255) / 256, B);
         hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
                            ex->d_pyr, (unsigned long long)G.pyr_bytes, L0);
         for (int l = 1; l < G.nlevels; ++l) {
             const DevLevel& D = ex->hlv[l];
-            dim3 g2((D.stride / 4 + 255) / 256, D.rows, B);
-            hipLaunchKernelGGL(k_resize, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
-                               ex->d_rx, ex->d_ry);
+            if (D.fast_resize) {
+                dim3 g2((D.cpr * D.h + 255) / 256, B);
+                hipLaunchKernelGGL(k_resize, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
+                                   ex->d_ry, ex->d_rg);
+            } else {
+                dim3 g2((D.w + 255) / 256, (D.h + 3) / 4, B);
+                hipLaunchKernelGGL(k_resize_generic, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
+                                   ex->d_rx, ex->d_ry);
+            }
         }
+        dim3 gb((ex->max_border_threads + 255) / 256, G.nlevels, B);
+        hipLaunchKernelGGL(k_borders, gb, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
     {

@@ -106,7 +106,7 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
     if (rc) return rc;
     g.width = width; g.height = height; g.nlevels = p.nlevels;
     g.lv.assign(p.nlevels, LevelGeom());
-    g.cells.clear(); g.rx.clear(); g.ry.clear();
+    g.cells.clear(); g.rx.clear(); g.ry.clear(); g.rg.clear();
     size_t off = 0;
     int cand_off = 0, kp_off = 0;
     g.out_cap = 0; g.max_cell_dim = 0;
@@ -120,6 +120,10 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
         L.kp_size = (float)(int)(kPatch * g.tables.scale[l]);
         L.quota = g.tables.quota[l];
         L.rows = L.h + 2 * kEdge;
+        L.cpr = (L.w + 15) / 16;
+        L.cpr_magic = (unsigned)((0x100000000ull + L.cpr - 1) / L.cpr);
+        for (uint32_t i = 0, n = (uint32_t)L.cpr * (uint32_t)L.h; i < n; ++i)     // the reciprocal must be exact over the index range
+            if ((uint32_t)(((uint64_t)i * L.cpr_magic) >> 32) != i / (uint32_t)L.cpr) { set_error("internal: chunk reciprocal inexact"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
         L.stride = (kRoiX + L.w + kEdge + 63) & ~63;
         L.offset = off;
         L.roi = off + (size_t)kEdge * L.stride + kRoiX;
@@ -184,8 +188,27 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
         kp_off += L.kp_cap;
         g.out_cap += L.kp_cap;
 
-        L.area2x = 0; L.rx_offset = (int)g.rx.size(); L.ry_offset = (int)g.ry.size();
-        if (l > 0) build_resize_tables(g.lv[l - 1].w, g.lv[l - 1].h, L.w, L.h, g.rx, g.ry, L.area2x);
+        L.area2x = 0; L.fast_resize = 0; L.rx_offset = (int)g.rx.size(); L.ry_offset = (int)g.ry.size();
+        L.rg_offset = (int)g.rg.size();
+        if (l > 0) {
+            build_resize_tables(g.lv[l - 1].w, g.lv[l - 1].h, L.w, L.h, g.rx, g.ry, L.area2x);
+            // fast kernel: every aligned group of four destination columns must read <= 8 consecutive source bytes
+            L.fast_resize = L.area2x ? 0 : 1;
+            for (int x0 = 0; x0 + 3 < L.w && L.fast_resize; x0 += 4)
+                if (g.rx[L.rx_offset + x0 + 3].sx + 1 - g.rx[L.rx_offset + x0].sx > 7) L.fast_resize = 0;
+            // group records cover whole 16-byte chunks; columns past the ROI repeat the last column (their
+            // output lands in the frame area and is overwritten by the border pass)
+            for (int x0 = 0; x0 < 16 * L.cpr && L.fast_resize; x0 += 4) {
+                ResizeGroup r{};
+                r.sx_first = g.rx[L.rx_offset + std::min(x0, L.w - 1)].sx;
+                for (int k = 0; k < 4; ++k) {
+                    const ResizeX& e = g.rx[L.rx_offset + std::min(x0 + k, L.w - 1)];
+                    r.offs |= (uint32_t)(e.sx - r.sx_first) << (8 * k);
+                    r.w[k] = (uint32_t)(uint16_t)e.a0 | ((uint32_t)(uint16_t)e.a1 << 16);
+                }
+                g.rg.push_back(r);
+            }
+        }
     }
     g.pyr_bytes = off;
     g.cand_total = cand_off;

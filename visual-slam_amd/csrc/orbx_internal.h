@@ -38,6 +38,9 @@ struct CellRec {
 };
 
 struct ResizeX { int32_t sx; int16_t a0, a1; };          // source column and Q11 weights of one destination column
+// Four adjacent destination columns: first source column, byte offset of each column's left neighbour
+// from it (one byte each), and the packed Q11 weights a0 | a1 << 16 of each column.  32 bytes.
+struct ResizeGroup { int32_t sx_first; uint32_t offs; uint32_t w[4]; uint32_t pad[2]; };
 struct ResizeY { int16_t sy0, sy1; int16_t b0, b1; };    // clamped source rows and Q11 weights of one destination row
 
 struct LevelGeom {
@@ -52,7 +55,11 @@ struct LevelGeom {
     int nIni; float hX;     // DistributeOctTree roots (src/ORBextractor.cc:542-544)
     int kp_offset, kp_cap;  // selected-keypoint slots of this level inside one frame's per-level array
     int area2x;             // resize from the previous level is an exact 2x2 decimation (OpenCV reroutes to INTER_AREA)
-    int rx_offset, ry_offset; // offsets into the ResizeX / ResizeY tables
+    int rx_offset, ry_offset; // offsets into the ResizeX / ResizeY tables (rx_offset is a multiple of 4)
+    int fast_resize;        // every aligned group of 4 destination columns reads <= 8 consecutive source bytes
+    int rg_offset;          // first ResizeGroup record of this level (4 per 16-byte chunk, cpr chunks)
+    int cpr;                // 16-byte chunks per ROI row, ceil(w/16)
+    unsigned cpr_magic;     // ceil(2^32 / cpr)
     float scale;            // mvScaleFactor[level]
     float kp_size;          // (float)(int)(31*scale), src/ORBextractor.cc:836,845
 };
@@ -64,6 +71,7 @@ struct Geometry {
     std::vector<CellRec> cells;
     std::vector<ResizeX> rx;
     std::vector<ResizeY> ry;
+    std::vector<ResizeGroup> rg;
     size_t pyr_bytes = 0;     // one frame's pyramid block
     int cand_total = 0;       // one frame's candidate slots (u32)
     int kp_total = 0;         // one frame's per-level selected-keypoint slots
