@@ -11,10 +11,10 @@ root = sys.argv[1]
 tab = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{root}/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-        name = re.sub(r"\(.*", "", name)
-        if not name.startswith("k_"):
+        m = re.search(r"\bk_[a-z0-9_]+", r["Kernel_Name"])
+        if not m:
             continue
+        name = m.group(0)
         tab[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 counters = sorted({c for k in tab.values() for c in k})
 lines = ["| kernel | launches | " + " | ".join(counters) + " |", "|---|---:|" + "---:|" * len(counters)]

@@ -12,8 +12,8 @@ with open(dst, "w") as f:
     f.write(f"# {title}\n\nSource: rocprofv3 --kernel-trace --stats (kernel_stats.csv); durations in microseconds.\n\n")
     f.write("| kernel | calls | total_us | avg_us | min_us | max_us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
     for r in rows:
-        name = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
-        name = re.sub(r"\(.*", "", name)[:70]
+        m = re.search(r"\bk_[a-z0-9_]+(<[^>]*>)?", r["Name"])
+        name = m.group(0) if m else re.sub(r"\(.*", "", r["Name"])[:70]
         f.write(f"| {name} | {r['Calls']} | {int(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.2f} | "
                 f"{int(r['MinNs'])/1e3:.2f} | {int(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |\n")
 print("wrote", dst)

@@ -57,6 +57,15 @@ typedef unsigned short us16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return *reinterpret_cast<const u32_unaligned*>(p); }
 
+// LDS hand-off between the lanes of one wavefront: DS operations of a wave execute in issue order,
+// so only the compiler has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     // one reflection is enough for |overshoot| <= 19 < len
@@ -220,35 +229,34 @@ __global__ __launch_bounds__(256) void k_borders(uint8_t* __restrict__ pyr, unsi
 // the set of local maxima does not depend on T; T only filters it.  A cell therefore needs one
 // score pass: keep maxima with s >= ini if there is one, otherwise those with s >= min.
 // ---------------------------------------------------------------------------------------------
-constexpr int kTileStride = 72;   // bytes per LDS tile row (cells are at most 59 wide: 59+6 <= 68)
-constexpr int kTileRows = 68;
-constexpr int kScoreStride = 64;
-constexpr int kMaxCellDim = 60;
+constexpr int kMaxCellDim = 60;      // cells are at most 59 wide (wCell = ceil(width / floor(width/30)))
+constexpr int kSmallCellDim = 38;    // the usual case (wCell 30..38): smaller LDS tiles, more resident wavefronts
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-// exact score of the pixel at tile address t (ring offsets in tile coordinates)
+// exact score of the pixel at tile address t (ring offsets in tile coordinates, row stride TS)
+template <int TS>
 __device__ __forceinline__ int fast_score(const uint8_t* t)
 {
     const int v = t[0];
     int d[16];
-    d[0] = v - t[3 * kTileStride];
-    d[1] = v - t[3 * kTileStride + 1];
-    d[2] = v - t[2 * kTileStride + 2];
-    d[3] = v - t[kTileStride + 3];
+    d[0] = v - t[3 * TS];
+    d[1] = v - t[3 * TS + 1];
+    d[2] = v - t[2 * TS + 2];
+    d[3] = v - t[TS + 3];
     d[4] = v - t[3];
-    d[5] = v - t[-kTileStride + 3];
-    d[6] = v - t[-2 * kTileStride + 2];
-    d[7] = v - t[-3 * kTileStride + 1];
-    d[8] = v - t[-3 * kTileStride];
-    d[9] = v - t[-3 * kTileStride - 1];
-    d[10] = v - t[-2 * kTileStride - 2];
-    d[11] = v - t[-kTileStride - 3];
+    d[5] = v - t[-TS + 3];
+    d[6] = v - t[-2 * TS + 2];
+    d[7] = v - t[-3 * TS + 1];
+    d[8] = v - t[-3 * TS];
+    d[9] = v - t[-3 * TS - 1];
+    d[10] = v - t[-2 * TS - 2];
+    d[11] = v - t[-TS - 3];
     d[12] = v - t[-3];
-    d[13] = v - t[kTileStride - 3];
-    d[14] = v - t[2 * kTileStride - 2];
-    d[15] = v - t[3 * kTileStride - 1];
+    d[13] = v - t[TS - 3];
+    d[14] = v - t[2 * TS - 2];
+    d[15] = v - t[3 * TS - 1];
     int lo3[16], hi3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -303,93 +311,120 @@ __device__ __forceinline__ uint32_t fast_pretest(const uint32_t (&m3)[3], const 
     return as_u32(pmax(dark, zero - bright));
 }
 
+// One wavefront per cell, four cells per workgroup; no workgroup barrier anywhere.
+//   tile load -> [pass 1: packed pretest of 256 pixels per round, survivors queued -> pass 2: exact score of the
+//   queued survivors whenever the queue fills, and at the end] -> pass 3: lane r owns row r of the cell: strict
+//   local maxima among the scored pixels, threshold choice, raster-ordered emission.
+// TS/TR: tile row stride (bytes) and rows, SS/SR: score tile stride and rows.
+constexpr int kFastQueue = 448;     // a flush leaves < 192 entries, one round adds <= 256
+
+template <int TS, int TR, int SS, int SR>
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
                                                     const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
                                                     uint32_t* __restrict__ cand, int cand_total,
                                                     uint16_t* __restrict__ cellcnt, int ncells, int iniTh, int minTh)
 {
-    __shared__ __align__(16) uint8_t tile[kTileRows * kTileStride];
-    __shared__ __align__(16) uint8_t score[(kMaxCellDim + 2) * kScoreStride];
-    __shared__ uint16_t queue[kMaxCellDim * kMaxCellDim];
-    __shared__ unsigned long long rowIni[64], rowMin[64];
-    __shared__ int qn;
+    __shared__ __align__(16) uint8_t s_tile[4][TR * TS];
+    __shared__ __align__(16) uint8_t s_score[4][SR * SS];
+    __shared__ unsigned long long s_scored[4][64];
+    __shared__ uint16_t s_queue[4][kFastQueue];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const CellRec c = cells[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cell = blockIdx.x * 4 + wave;
+    if (cell >= ncells) return;
+    const CellRec c = cells[cell];
     const DevLevel& L = lv[c.level];
     const uint8_t* src = pyr + (unsigned long long)blockIdx.y * pyr_bytes + L.roi + (long long)c.y0 * L.stride + c.x0;
+    uint8_t* tile = s_tile[wave];
+    uint8_t* score = s_score[wave];
+    unsigned long long* scored = s_scored[wave];
+    uint16_t* queue = s_queue[wave];
     const int cw = c.cw, ch = c.ch;
     const int tw = cw + 6, th = ch + 6;
-    const int dpr = (tw + 3) >> 2; // dwords per tile row
-    for (int i = tid; i < th * dpr; i += 256) {
-        const int r = i / dpr, d = i - r * dpr;
-        *reinterpret_cast<uint32_t*>(&tile[r * kTileStride + 4 * d]) = load_u32(src + (long long)r * L.stride + 4 * d);
+    const int dpr = (tw + 3) >> 2; // dwords per tile row (<= 17)
+    {
+        const int d = lane & 15;
+        uint32_t* trow = reinterpret_cast<uint32_t*>(tile);
+        for (int r = lane >> 4; r < th; r += 4) {
+            const uint8_t* p = src + (long long)r * L.stride + 4 * d;
+            if (d < dpr) trow[r * (TS / 4) + d] = load_u32(p);
+            if (d + 16 < dpr) trow[r * (TS / 4) + d + 16] = load_u32(p + 64);
+        }
     }
-    for (int i = tid; i < (ch + 2) * (kScoreStride / 4); i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
-    if (tid < 64) { rowIni[tid] = 0; rowMin[tid] = 0; }
-    if (tid == 0) qn = 0;
-    __syncthreads();
+    for (int i = lane; i < (ch + 2) * (SS / 4); i += 64) reinterpret_cast<uint32_t*>(score)[i] = 0;
+    scored[lane] = 0;
+    wave_sync();
 
     const int lowTh = min(iniTh, minTh);
-    // pass 1: four pixels per thread, cheap necessary test on packed pairs; survivors are queued
-    const int gpr = (cw + 3) >> 2;
-    for (int gi = tid; gi < gpr * ch; gi += 256) {
-        const int y = gi / gpr, g = gi - y * gpr;
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(&tile[y * kTileStride]) + g;   // tile row y = image row y-3
-        constexpr int RS = kTileStride / 4;
-        const uint32_t m3[3] = {row[0], row[1], row[2]};
-        const uint32_t m2[3] = {row[RS], row[RS + 1], row[RS + 2]};
-        const uint32_t cc[3] = {row[3 * RS], row[3 * RS + 1], row[3 * RS + 2]};
-        const uint32_t p2[3] = {row[5 * RS], row[5 * RS + 1], row[5 * RS + 2]};
-        const uint32_t p3[3] = {row[6 * RS], row[6 * RS + 1], row[6 * RS + 2]};
-        const uint32_t t01 = fast_pretest<0>(m3, m2, cc, p2, p3);
-        const uint32_t t23 = fast_pretest<2>(m3, m2, cc, p2, p3);
-        const int x = 4 * g;
-        const bool pass[4] = {(int)(short)(t01 & 0xFFFFu) > lowTh && x < cw, ((int)t01 >> 16) > lowTh && x + 1 < cw,
-                              (int)(short)(t23 & 0xFFFFu) > lowTh && x + 2 < cw, ((int)t23 >> 16) > lowTh && x + 3 < cw};
+    const int gpr = (cw + 3) >> 2;                 // groups of four pixels per row (<= 15)
+    const int gsh = gpr <= 8 ? 3 : 4;
+    const int g = lane & ((1 << gsh) - 1);
+    const int rows_per_round = 64 >> gsh;
+    const int x = 4 * g;
+    const uint32_t colmask = g < gpr ? (1u << min(cw - x, 4)) - 1u : 0u;   // pixels past the cell's last column
+    int nq = 0;                                     // wave-uniform queue fill
+    for (int y0 = 0; y0 < ch; y0 += rows_per_round) {
+        const int y = y0 + (lane >> gsh);
+        uint32_t pm = 0;
+        if (y < ch && colmask) {
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(&tile[y * TS]) + g;   // tile row y = image row y-3
+            constexpr int RS = TS / 4;
+            const uint32_t m3[3] = {row[0], row[1], row[2]};
+            const uint32_t m2[3] = {row[RS], row[RS + 1], row[RS + 2]};
+            const uint32_t cc[3] = {row[3 * RS], row[3 * RS + 1], row[3 * RS + 2]};
+            const uint32_t p2[3] = {row[5 * RS], row[5 * RS + 1], row[5 * RS + 2]};
+            const uint32_t p3[3] = {row[6 * RS], row[6 * RS + 1], row[6 * RS + 2]};
+            const uint32_t t01 = fast_pretest<0>(m3, m2, cc, p2, p3);
+            const uint32_t t23 = fast_pretest<2>(m3, m2, cc, p2, p3);
+            pm = ((int)(short)(t01 & 0xFFFFu) > lowTh ? 1u : 0u) | (((int)t01 >> 16) > lowTh ? 2u : 0u) |
+                 ((int)(short)(t23 & 0xFFFFu) > lowTh ? 4u : 0u) | (((int)t23 >> 16) > lowTh ? 8u : 0u);
+            pm &= colmask;
+        }
+        // queue the survivors of this round (wave-level compaction, one ballot per pixel slot)
+        const int idx = y * 64 + x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned long long m = __ballot(pass[j]);
-            if (m) {
-                int base = 0;
-                if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&qn, __popcll(m));
-                base = __shfl(base, __ffsll((long long)m) - 1, 64);
-                if (pass[j]) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y * 64 + x + j);
+            const bool on = (pm >> j) & 1u;
+            const unsigned long long m = __ballot(on);
+            if (on) queue[nq + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(idx + j);
+            nq += __popcll(m);
+        }
+        if (nq >= 192 || y0 + rows_per_round >= ch) {
+            // pass 2: exact score of the queued survivors
+            wave_sync();
+            for (int e = lane; e < nq; e += 64) {
+                const int i = queue[e];
+                const int yy = i >> 6, xx = i & 63;
+                const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
+                if (sc >= lowTh && sc >= 1) {
+                    score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
+                    atomicOr(&scored[yy], 1ull << xx);
+                }
             }
+            wave_sync();
+            nq = 0;
         }
     }
-    __syncthreads();
-    // pass 2: exact score of the survivors
-    const int nq = qn;
-    for (int e = tid; e < nq; e += 256) {
-        const int i = queue[e];
-        const int y = i >> 6, x = i & 63;
-        const int s = fast_score(&tile[(y + 3) * kTileStride + x + 3]);
-        if (s >= lowTh && s >= 1) score[(y + 1) * kScoreStride + x + 1] = (uint8_t)s;
-    }
-    __syncthreads();
-    // pass 3: strict local maxima inside the cell, recorded as one 64-bit mask per row
+    // pass 3: lane r owns row r: strict local maxima inside the cell among the scored pixels
     const int tIni = max(iniTh, 1), tMin = max(minTh, 1);
-    for (int e = tid; e < nq; e += 256) {
-        const int i = queue[e];
-        const int y = i >> 6, x = i & 63;
-        const uint8_t* sp = &score[(y + 1) * kScoreStride + x + 1];
-        const int s = sp[0];
-        if (s > 0) {
-            const bool mx = s > sp[-1] && s > sp[1] &&
-                            s > sp[-kScoreStride - 1] && s > sp[-kScoreStride] && s > sp[-kScoreStride + 1] &&
-                            s > sp[kScoreStride - 1] && s > sp[kScoreStride] && s > sp[kScoreStride + 1];
+    unsigned long long mi = 0, mm = 0;
+    if (lane < ch) {
+        unsigned long long todo = scored[lane];
+        while (todo) {
+            const int xx = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint8_t* sp = &score[(lane + 1) * SS + xx + 1];
+            const int sc = sp[0];
+            const bool mx = sc > sp[-1] && sc > sp[1] &&
+                            sc > sp[-SS - 1] && sc > sp[-SS] && sc > sp[-SS + 1] &&
+                            sc > sp[SS - 1] && sc > sp[SS] && sc > sp[SS + 1];
             if (mx) {
-                if (s >= tMin) atomicOr(&rowMin[y], 1ull << x);
-                if (s >= tIni) atomicOr(&rowIni[y], 1ull << x);
+                if (sc >= tMin) mm |= 1ull << xx;
+                if (sc >= tIni) mi |= 1ull << xx;
             }
         }
     }
-    __syncthreads();
-    // pass 4 (first wavefront): lane r owns row r; raster-ordered emission into this cell's slots
-    if (tid >= 64) return;
-    const unsigned long long mi = lane < ch ? rowIni[lane] : 0ull;
-    const unsigned long long mm = lane < ch ? rowMin[lane] : 0ull;
+    // threshold choice (FAST at iniThFAST, and only if that finds nothing, at minThFAST) and emission
     unsigned long long mask = __any(mi != 0ull) ? mi : mm;
     const int cnt = __popcll(mask);
     int inc = cnt;
@@ -398,13 +433,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     int pos = inc - cnt;
     uint32_t* out = cand + (unsigned long long)blockIdx.y * cand_total + L.cand_offset + c.slot;
     while (mask) {
-        const int x = __ffsll((long long)mask) - 1;
+        const int xx = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        const int s = score[(lane + 1) * kScoreStride + x + 1];
-        if (pos < c.cap) out[pos] = ((uint32_t)(x + 3 + c.offx) << 20) | ((uint32_t)(lane + 3 + c.offy) << 8) | (uint32_t)s;
+        const int sc = score[(lane + 1) * SS + xx + 1];
+        if (pos < c.cap) out[pos] = ((uint32_t)(xx + 3 + c.offx) << 20) | ((uint32_t)(lane + 3 + c.offy) << 8) | (uint32_t)sc;
         ++pos;
     }
-    if (lane == 0) cellcnt[(unsigned long long)blockIdx.y * ncells + blockIdx.x] = (uint16_t)min(total, c.cap);
+    if (lane == 0) cellcnt[(unsigned long long)blockIdx.y * ncells + cell] = (uint16_t)min(total, c.cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -499,15 +534,6 @@ __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* _
 constexpr int kPatchW = 43, kPatchStride = 44, kBlurW = 37, kBlurStride = 40;
 constexpr int kHRows = 44;      // rows per column of the transposed horizontal-pass buffer (43 used, even for dword pairs)
 constexpr int kHCols = 40;      // columns written by the horizontal pass (37 used)
-
-// LDS hand-off between the lanes of one wavefront: DS operations of a wave execute in issue order,
-// so only the compiler has to be kept from moving accesses across this point.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -877,10 +903,16 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
     {
-        dim3 grid((unsigned)G.cells.size(), B);
-        hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells,
-                           ex->d_cand, G.cand_total, ex->d_cellcnt, (int)G.cells.size(), ex->params.ini_th_fast,
-                           ex->params.min_th_fast);
+        const int nc = (int)G.cells.size();
+        dim3 grid((nc + 3) / 4, B);
+        if (G.max_cell_dim <= kSmallCellDim)
+            hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 48, kSmallCellDim + 2>), grid, dim3(256), 0, st, ex->d_pyr,
+                               (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total, ex->d_cellcnt, nc,
+                               ex->params.ini_th_fast, ex->params.min_th_fast);
+        else
+            hipLaunchKernelGGL((k_fast_cells<72, kMaxCellDim + 8, 64, kMaxCellDim + 2>), grid, dim3(256), 0, st, ex->d_pyr,
+                               (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total, ex->d_cellcnt, nc,
+                               ex->params.ini_th_fast, ex->params.min_th_fast);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
     {
