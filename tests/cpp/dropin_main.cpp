@@ -1,0 +1,58 @@
+// Exercises the C++ drop-in classes the way the reference's callers do (Frame::ExtractORB,
+// Tracking::MonocularInitialization) and dumps the results for the Python parity test.
+#include "../../visual-slam_amd/cpp/ORBextractor.h"
+#include "../../visual-slam_amd/cpp/ORBmatcher.h"
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+
+static void dump(FILE* f, const void* p, size_t n) { fwrite(p, 1, n, f); }
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: dropin_main <out.bin>\n"); return 2; }
+    const int w = 640, h = 480;
+    cv::Mat im1(h, w, CV_8UC1), im2(h, w, CV_8UC1);
+    orbx_synth_frame(12, w, h, im1.ptr(), (ptrdiff_t)im1.step);
+    // second view: first view shifted by (5,3), as in the Python tests (no extra noise here)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) im2.at<unsigned char>(y, x) = im1.at<unsigned char>((y - 3 + h) % h, (x - 5 + w) % w);
+
+    ORB_SLAM2::ORBextractor* ini = new ORB_SLAM2::ORBextractor(2000, 1.2f, 8, 20, 7);   // Tracking.cc:131-137
+    std::vector<cv::KeyPoint> k1, k2;
+    cv::Mat d1, d2;
+    (*ini)(im1, cv::Mat(), k1, d1);
+    cv::Mat pyr3 = ini->mvImagePyramid[3].clone();
+    const int pyr3_step = (int)ini->mvImagePyramid[3].step;
+    (*ini)(im2, cv::Mat(), k2, d2);
+    cv::Mat empty;
+    std::vector<cv::KeyPoint> untouched(3);
+    (*ini)(empty, cv::Mat(), untouched, d1);      // silent return, outputs untouched
+    if (untouched.size() != 3) return 3;
+
+    ORB_SLAM2::FrameView F1, F2;
+    F1.keysUn = &k1; F1.descriptors = &d1; F1.minX = 0; F1.maxX = w; F1.minY = 0; F1.maxY = h;
+    F2.keysUn = &k2; F2.descriptors = &d2; F2.minX = 0; F2.maxX = w; F2.minY = 0; F2.maxY = h;
+    std::vector<cv::Point2f> prev(k1.size());
+    for (size_t i = 0; i < k1.size(); ++i) prev[i] = k1[i].pt;
+    std::vector<int> m12;
+    ORB_SLAM2::ORBmatcher matcher(0.9, true);                                          // Tracking.cc:652-653
+    const int nm = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
+    const int dist = ORB_SLAM2::ORBmatcher::DescriptorDistance(d1.row(0), d2.row(0));
+
+    FILE* f = fopen(argv[1], "wb");
+    if (!f) return 4;
+    int hdr[8] = {(int)k1.size(), (int)k2.size(), nm, dist, pyr3.cols, pyr3.rows, pyr3_step, ini->GetLevels()};
+    dump(f, hdr, sizeof(hdr));
+    dump(f, k1.data(), k1.size() * sizeof(cv::KeyPoint));
+    dump(f, d1.ptr(), (size_t)d1.rows * 32);
+    dump(f, k2.data(), k2.size() * sizeof(cv::KeyPoint));
+    dump(f, d2.ptr(), (size_t)d2.rows * 32);
+    dump(f, m12.data(), m12.size() * sizeof(int));
+    dump(f, pyr3.ptr(), (size_t)pyr3.rows * pyr3.cols);
+    std::vector<float> sf = ini->GetScaleFactors();
+    dump(f, sf.data(), sf.size() * sizeof(float));
+    fclose(f);
+    printf("dropin ok: %zu / %zu keypoints, %d initial matches\n", k1.size(), k2.size(), nm);
+    return 0;
+}

@@ -1,0 +1,47 @@
+"""The C++ drop-in classes (visual-slam_amd/cpp: ORBextractor, ORBmatcher) driven like the reference's callers,
+checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_cpp_dropin_classes(vsa, oracle, tmp_path):
+    exe = os.path.join(HERE, "cpp", "dropin_main")
+    assert os.path.exists(exe), "build tests/cpp first (make -C tests/cpp, done by __graft_entry__.build())"
+    out = tmp_path / "dropin.bin"
+    env = dict(os.environ)
+    # the driver has no torch in its process: it must bind the system HIP runtime
+    subprocess.check_call([exe, str(out)], env=env, timeout=120)
+    raw = out.read_bytes()
+    n1, n2, nm, dist, pw, ph, pstep, nlev = np.frombuffer(raw, np.int32, 8)
+    off = 32
+    k1 = np.frombuffer(raw, vsa.KEYPOINT_DTYPE, n1, off); off += n1 * 28
+    d1 = np.frombuffer(raw, np.uint8, n1 * 32, off).reshape(n1, 32); off += n1 * 32
+    k2 = np.frombuffer(raw, vsa.KEYPOINT_DTYPE, n2, off); off += n2 * 28
+    d2 = np.frombuffer(raw, np.uint8, n2 * 32, off).reshape(n2, 32); off += n2 * 32
+    m12 = np.frombuffer(raw, np.int32, n1, off); off += n1 * 4
+    pyr3 = np.frombuffer(raw, np.uint8, pw * ph, off).reshape(ph, pw); off += pw * ph
+    sf = np.frombuffer(raw, np.float32, nlev, off)
+
+    w, h = 640, 480
+    im1 = vsa.synth_frame(12, w, h)
+    im2 = np.roll(im1, (3, 5), axis=(0, 1))
+    oex = oracle.Extractor(oracle.make_params(2000))
+    ok1, od1 = oex.extract(im1)
+    want_pyr3 = oex.level_padded(3)
+    ok2, od2 = oex.extract(im2)
+    assert n1 == len(ok1) and n2 == len(ok2)
+    assert np.array_equal(k1, ok1.astype(vsa.KEYPOINT_DTYPE)) and np.array_equal(d1, od1)
+    assert np.array_equal(k2, ok2.astype(vsa.KEYPOINT_DTYPE)) and np.array_equal(d2, od2)
+    # mvImagePyramid[3]: ROI of the (w+38) x (h+38) buffer
+    assert pstep == pw + 38 and np.array_equal(pyr3, want_pyr3[19:-19, 19:-19])
+    prev = np.stack([ok1["x"], ok1["y"]], 1).astype(np.float32)
+    om12, onm, _ = oracle.search_for_initialization(ok1, od1, ok2, od2, (0.0, float(w), 0.0, float(h)), prev, 100, 0.9, True)
+    assert nm == onm and np.array_equal(m12, om12) and nm > 100
+    assert dist == oracle.descriptor_distance(od1[0], od2[0])
+    assert np.array_equal(sf, oex.tables()["scale"])

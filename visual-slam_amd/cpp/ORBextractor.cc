@@ -1,0 +1,89 @@
+#include "ORBextractor.h"
+#include <stdexcept>
+#include <string>
+#include <cstring>
+
+namespace ORB_SLAM2
+{
+
+static void check(int status, const char* what)
+{
+    if (status != ORBX_OK)
+        throw std::runtime_error(std::string(what) + ": " + orbx_status_string(status) + " (" + orbx_last_error() + ")");
+}
+
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
+    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST)
+{
+    mParams.nfeatures = _nfeatures; mParams.scale_factor = _scaleFactor; mParams.nlevels = _nlevels;
+    mParams.ini_th_fast = _iniThFAST; mParams.min_th_fast = _minThFAST; mParams.blur_rounding = 0;
+    mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels); umax.resize(16);
+    check(orbx_scale_tables(&mParams, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                            mvInvLevelSigma2.data(), mnFeaturesPerLevel.data(), umax.data()), "ORBextractor");
+    mvImagePyramid.resize(nlevels);
+}
+
+ORBextractor::~ORBextractor() { orbx_extractor_destroy(mpContext); }
+
+void ORBextractor::SetDevice(int device)
+{
+    if (device != mnDevice) { orbx_extractor_destroy(mpContext); mpContext = nullptr; mnDevice = device; }
+}
+
+void ORBextractor::SetBlurRounding(int mode)
+{
+    if (mode != mParams.blur_rounding) { orbx_extractor_destroy(mpContext); mpContext = nullptr; mParams.blur_rounding = mode; }
+}
+
+void ORBextractor::EnsureContext(int width, int height)
+{
+    if (mpContext && width == mnWidth && height == mnHeight) return;
+    orbx_extractor_destroy(mpContext);
+    mpContext = nullptr;
+    check(orbx_extractor_create(&mParams, width, height, 1, mnDevice, &mpContext), "ORBextractor: context");
+    mnWidth = width; mnHeight = height;
+    mvStaging.resize(orbx_keypoint_capacity(&mParams, width, height));
+}
+
+void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                              cv::OutputArray _descriptors)
+{
+    if (_image.empty())
+        return;
+    const cv::Mat& image = _image;
+    if (image.type() != CV_8UC1) throw std::runtime_error("ORBextractor: image must be CV_8UC1");
+    EnsureContext(image.cols, image.rows);
+
+    const int cap = (int)mvStaging.size();
+    cv::Mat desc(cap, 32, CV_8U);
+    int n = 0;
+    check(orbx_extract(mpContext, image.ptr(), (ptrdiff_t)image.step, mvStaging.data(), desc.ptr(), cap, &n), "ORBextractor: extract");
+
+    if (n == 0)
+        _descriptors.release();
+    else {
+        _descriptors.create(n, 32, CV_8U);
+        std::memcpy(_descriptors.ptr(), desc.ptr(), (size_t)n * 32);
+    }
+    _keypoints.clear();
+    _keypoints.reserve(n);
+    static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "keypoint layouts must agree");
+    for (int i = 0; i < n; ++i) {
+        const orbx_keypoint& k = mvStaging[i];
+        _keypoints.push_back(cv::KeyPoint(k.x, k.y, k.size, k.angle, k.response, k.octave, k.class_id));
+    }
+
+    if (mbDownloadPyramid) {
+        for (int level = 0; level < nlevels; ++level) {
+            int w = 0, h = 0;
+            check(orbx_level_size(&mParams, image.cols, image.rows, level, &w, &h), "ORBextractor: level size");
+            cv::Mat temp(h + 38, w + 38, CV_8UC1);
+            check(orbx_pyramid_level(mpContext, 0, level, temp.ptr(), (ptrdiff_t)temp.step), "ORBextractor: pyramid");
+            mvImagePyramid[level] = temp(cv::Rect(19, 19, w, h));
+        }
+    }
+}
+
+} //namespace ORB_SLAM2

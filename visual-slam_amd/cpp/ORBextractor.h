@@ -1,0 +1,71 @@
+// Drop-in for the reference's ORB_SLAM2::ORBextractor (include/ORBextractor.h:74-282): same constructor,
+// operator(), getters and the public mvImagePyramid member; the work runs on the MI355X through the C ABI
+// of include/orbx.h.  ExtractorNode / DistributeOctTree / ComputePyramid are not members here: they live
+// in the device kernels.
+#ifndef ORBX_ORBEXTRACTOR_H
+#define ORBX_ORBEXTRACTOR_H
+
+#include <vector>
+#include "cv_compat.h"
+#include "../../include/orbx.h"
+
+namespace ORB_SLAM2
+{
+
+class ORBextractor
+{
+public:
+    enum {HARRIS_SCORE=0, FAST_SCORE=1 };
+
+    // include/ORBextractor.h:83-84
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+    ~ORBextractor();
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // include/ORBextractor.h:102-104.  The mask is ignored, as in the reference.  An empty image returns
+    // silently and leaves the outputs untouched (src/ORBextractor.cc:1045-1046); any other failure throws
+    // std::runtime_error where the reference would surface a cv::Exception.
+    void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
+
+    int inline GetLevels() { return nlevels; }
+    float inline GetScaleFactor() { return (float)scaleFactor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // include/ORBextractor.h:150: level images as ROIs of (w+38) x (h+38) buffers with the REFLECT_101 frame,
+    // refreshed by every operator() call (read by Frame::ComputeStereoMatches, src/Frame.cc:563-580).
+    std::vector<cv::Mat> mvImagePyramid;
+
+    // Extensions (no counterpart in the reference): skip the device-to-host copy of the pyramid when the
+    // caller does not read mvImagePyramid (monocular tracking); choose the GPU; pick the GaussianBlur tie
+    // rounding (orbx_params::blur_rounding).
+    void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
+    void SetDevice(int device);
+    void SetBlurRounding(int mode);
+    orbx_extractor* Handle() { return mpContext; }
+
+protected:
+    void EnsureContext(int width, int height);
+
+    int nfeatures;
+    double scaleFactor;      // a double in the reference too (include/ORBextractor.h:223)
+    int nlevels;
+    int iniThFAST;
+    int minThFAST;
+    std::vector<int> mnFeaturesPerLevel;
+    std::vector<int> umax;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+
+    orbx_params mParams;
+    orbx_extractor* mpContext = nullptr;
+    int mnWidth = 0, mnHeight = 0, mnDevice = -1;
+    bool mbDownloadPyramid = true;
+    std::vector<orbx_keypoint> mvStaging;
+};
+
+} //namespace ORB_SLAM2
+
+#endif

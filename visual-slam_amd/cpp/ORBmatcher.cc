@@ -1,0 +1,132 @@
+#include "ORBmatcher.h"
+#include <stdexcept>
+#include <string>
+#include <cstring>
+
+namespace ORB_SLAM2
+{
+
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+
+static void check(int status, const char* what)
+{
+    if (status != ORBX_OK)
+        throw std::runtime_error(std::string(what) + ": " + orbx_status_string(status) + " (" + orbx_last_error() + ")");
+}
+
+static const orbx_keypoint* as_orbx(const std::vector<cv::KeyPoint>& v)
+{
+    static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "keypoint layouts must agree");
+    return reinterpret_cast<const orbx_keypoint*>(v.data());
+}
+
+static std::vector<unsigned char> packed_rows(const cv::Mat& d)
+{
+    std::vector<unsigned char> out((size_t)d.rows * 32);
+    for (int r = 0; r < d.rows; ++r) std::memcpy(out.data() + (size_t)r * 32, d.ptr(r), 32);
+    return out;
+}
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+ORBmatcher::~ORBmatcher() { orbx_matcher_destroy(mpContext); }
+
+void ORBmatcher::SetDevice(int device)
+{
+    if (device != mnDevice) { orbx_matcher_destroy(mpContext); mpContext = nullptr; mnDevice = device; }
+}
+
+orbx_matcher* ORBmatcher::Context()
+{
+    if (!mpContext) check(orbx_matcher_create(mnDevice, &mpContext), "ORBmatcher: context");
+    return mpContext;
+}
+
+int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b)
+{
+    return orbx_descriptor_distance(a.ptr(), b.ptr());
+}
+
+void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3)
+{
+    std::vector<int32_t> sizes(L);
+    for (int i = 0; i < L; ++i) sizes[i] = (int32_t)histo[i].size();
+    orbx_compute_three_maxima(sizes.data(), L, &ind1, &ind2, &ind3);
+}
+
+int ORBmatcher::SearchForInitialization(const FrameView& F1, const FrameView& F2, std::vector<cv::Point2f>& vbPrevMatched,
+                                        std::vector<int>& vnMatches12, int windowSize)
+{
+    const int n1 = (int)F1.keysUn->size(), n2 = (int)F2.keysUn->size();
+    vnMatches12.assign(n1, -1);
+    if ((int)vbPrevMatched.size() != n1) throw std::runtime_error("SearchForInitialization: vbPrevMatched size");
+    std::vector<unsigned char> d1 = packed_rows(*F1.descriptors), d2 = packed_rows(*F2.descriptors);
+    int nmatches = 0;
+    static_assert(sizeof(cv::Point2f) == 8, "Point2f layout");
+    check(orbx_search_for_initialization(Context(), as_orbx(*F1.keysUn), d1.data(), n1, as_orbx(*F2.keysUn), d2.data(), n2,
+                                         F2.minX, F2.maxX, F2.minY, F2.maxY, reinterpret_cast<float*>(vbPrevMatched.data()),
+                                         windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &nmatches),
+          "SearchForInitialization");
+    return nmatches;
+}
+
+namespace {
+struct QueryArrays {
+    std::vector<float> u, v, r, ur, angle; std::vector<int32_t> level; std::vector<unsigned char> desc;
+    explicit QueryArrays(const std::vector<ProjectedQuery>& q)
+    {
+        const size_t n = q.size();
+        u.resize(n); v.resize(n); r.resize(n); ur.resize(n); angle.resize(n); level.resize(n); desc.resize(n * 32);
+        for (size_t i = 0; i < n; ++i) {
+            u[i] = q[i].u; v[i] = q[i].v; r[i] = q[i].radius; ur[i] = q[i].uRight; angle[i] = q[i].angle; level[i] = q[i].level;
+            std::memcpy(desc.data() + i * 32, q[i].descriptor, 32);
+        }
+    }
+};
+}
+
+int ORBmatcher::SearchByProjection(const FrameView& F, const std::vector<ProjectedQuery>& vQueries, std::vector<int>& vnClaimed)
+{
+    const int n2 = (int)F.keysUn->size();
+    if ((int)vnClaimed.size() != n2) throw std::runtime_error("SearchByProjection: vnClaimed size");
+    QueryArrays q(vQueries);
+    std::vector<unsigned char> d2 = packed_rows(*F.descriptors);
+    int nmatches = 0;
+    check(orbx_search_by_projection_mappoints(Context(), q.u.data(), q.v.data(), q.r.data(), q.ur.data(), q.level.data(), q.desc.data(),
+                                              (int)vQueries.size(), as_orbx(*F.keysUn), d2.data(), F.uRight ? F.uRight->data() : nullptr, n2,
+                                              F.minX, F.maxX, F.minY, F.maxY, mfNNratio, vnClaimed.data(), &nmatches),
+          "SearchByProjection");
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(const FrameView& F, const std::vector<ProjectedQuery>& vQueries, std::vector<int>& vnClaimed, int mode,
+                                   int thDist)
+{
+    const int n2 = (int)F.keysUn->size();
+    if ((int)vnClaimed.size() != n2) throw std::runtime_error("SearchByProjection: vnClaimed size");
+    QueryArrays q(vQueries);
+    std::vector<unsigned char> d2 = packed_rows(*F.descriptors);
+    int nmatches = 0;
+    check(orbx_search_by_projection_lastframe(Context(), q.u.data(), q.v.data(), q.r.data(), q.ur.data(), q.level.data(), q.angle.data(),
+                                              q.desc.data(), (int)vQueries.size(), as_orbx(*F.keysUn), d2.data(),
+                                              F.uRight ? F.uRight->data() : nullptr, n2, F.minX, F.maxX, F.minY, F.maxY, mode, thDist,
+                                              mbCheckOrientation ? 1 : 0, vnClaimed.data(), &nmatches),
+          "SearchByProjection");
+    return nmatches;
+}
+
+void ORBmatcher::StereoRowSearch(const std::vector<cv::KeyPoint>& vKeysLeft, const cv::Mat& descLeft,
+                                 const std::vector<cv::KeyPoint>& vKeysRight, const cv::Mat& descRight,
+                                 const std::vector<float>& vScaleFactors, int nRows, float minD, float maxD,
+                                 std::vector<int>& vBestDist, std::vector<int>& vBestIdxR)
+{
+    const int nl = (int)vKeysLeft.size(), nr = (int)vKeysRight.size();
+    vBestDist.assign(nl, -1); vBestIdxR.assign(nl, -1);
+    std::vector<unsigned char> dl = packed_rows(descLeft), dr = packed_rows(descRight);
+    check(orbx_stereo_match(Context(), as_orbx(vKeysLeft), dl.data(), nl, as_orbx(vKeysRight), dr.data(), nr, vScaleFactors.data(),
+                            (int)vScaleFactors.size(), nRows, minD, maxD, vBestDist.data(), vBestIdxR.data()),
+          "StereoRowSearch");
+}
+
+} // namespace ORB_SLAM2

@@ -1,0 +1,83 @@
+// Drop-in for the matching loops of the reference's ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:56-330).
+// Frame / KeyFrame / MapPoint belong to the reference's map data model and are not rebuilt here; the
+// Search* methods take a FrameView (the fields of Frame the reference reads) and plain query arrays.
+// A maintainer of the reference keeps the original signatures and forwards to these from the places cited
+// on each method.
+#ifndef ORBX_ORBMATCHER_H
+#define ORBX_ORBMATCHER_H
+
+#include <vector>
+#include "cv_compat.h"
+#include "../../include/orbx.h"
+
+namespace ORB_SLAM2
+{
+
+// What the matchers read from a Frame: mvKeysUn, mDescriptors (N x 32), mvuRight, and the static image bounds
+// mnMinX.. (src/Frame.cc:457-463).
+struct FrameView {
+    const std::vector<cv::KeyPoint>* keysUn = nullptr;
+    const cv::Mat* descriptors = nullptr;
+    const std::vector<float>* uRight = nullptr;   // may be null (monocular)
+    float minX = 0, maxX = 0, minY = 0, maxY = 0;
+};
+
+// One projected map point / last-frame keypoint (the values the reference computes before its candidate loop).
+struct ProjectedQuery {
+    float u, v;          // projection in the current frame
+    float radius;        // search radius, already multiplied by the scale factor of the level
+    float uRight;        // projected right-image column (stereo consistency test); ignored when FrameView::uRight is null
+    int level;           // predicted level (map points) or octave of the last-frame keypoint
+    float angle;         // keypoint angle of the source observation (rotation histogram)
+    const unsigned char* descriptor; // 32 bytes
+};
+
+class ORBmatcher
+{
+public:
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true);
+    ~ORBmatcher();
+    ORBmatcher(const ORBmatcher&) = delete;
+    ORBmatcher& operator=(const ORBmatcher&) = delete;
+
+    // src/ORBmatcher.cc:1650-1666
+    static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
+
+    // src/ORBmatcher.cc:408-523.  vbPrevMatched and vnMatches12 as in the reference.
+    int SearchForInitialization(const FrameView& F1, const FrameView& F2, std::vector<cv::Point2f>& vbPrevMatched,
+                                std::vector<int>& vnMatches12, int windowSize = 10);
+
+    // src/ORBmatcher.cc:45-129 (candidate loop and acceptance).  vnClaimed[i] >= 0 marks frame keypoints that already
+    // hold a map point with observations; a new match stores the query index.  Returns the number of matches.
+    int SearchByProjection(const FrameView& F, const std::vector<ProjectedQuery>& vQueries, std::vector<int>& vnClaimed);
+
+    // src/ORBmatcher.cc:1331-1473 and 1475-1602: best-1 within thDist (TH_HIGH or ORBdist), rotation histogram.
+    // mode 0: levels level-1..level+1, 1: forward motion (>= level), 2: backward (0..level).
+    int SearchByProjection(const FrameView& CurrentFrame, const std::vector<ProjectedQuery>& vQueries, std::vector<int>& vnClaimed,
+                           int mode, int thDist);
+
+    // Frame::ComputeStereoMatches, Hamming part (src/Frame.cc:466-549).
+    void StereoRowSearch(const std::vector<cv::KeyPoint>& vKeysLeft, const cv::Mat& descLeft,
+                         const std::vector<cv::KeyPoint>& vKeysRight, const cv::Mat& descRight,
+                         const std::vector<float>& vScaleFactors, int nRows, float minD, float maxD,
+                         std::vector<int>& vBestDist, std::vector<int>& vBestIdxR);
+
+    static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
+
+    static const int TH_LOW;
+    static const int TH_HIGH;
+    static const int HISTO_LENGTH;
+
+    void SetDevice(int device);
+
+protected:
+    orbx_matcher* Context();
+    float mfNNratio;
+    bool mbCheckOrientation;
+    orbx_matcher* mpContext = nullptr;
+    int mnDevice = -1;
+};
+
+} // namespace ORB_SLAM2
+
+#endif
