@@ -106,6 +106,10 @@ int orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, uint32_
  * keys packed as above; out receives the selected keys in list order. */
 int orbx_distribute_octree(int device, const uint32_t* packed_keys, int n, int minX, int maxX, int minY, int maxY,
                            int N, uint32_t* out, int cap, int* n_out);
+/* Same, choosing where the kernel keeps the keys: 0 = in LDS when they fit (the production path),
+ * 1 = always device memory (the path taken when a level has more keys than the LDS arrays hold).  For parity tests. */
+int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, int minX, int maxX, int minY, int maxY,
+                              int N, uint32_t* out, int cap, int* n_out, int key_storage);
 
 /* Per-stage device time of the last batch, measured with HIP events on the launch stream when
  * profiling is switched on (no counterpart in the reference).  Stage order: ORBX_STAGE_*. */

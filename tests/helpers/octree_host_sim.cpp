@@ -18,5 +18,7 @@ extern "C" int otsim_distribute(const uint32_t* keys, int nk, int minX, int maxX
     std::vector<int32_t> cc(4 * NC), candPos(NC), pi(NC), cByPi(NC), keep(NC), posToCand(NC), scal(16), tmp(8);
     std::vector<uint16_t> nodeOf(nk > 0 ? nk : 1);
     OtShared s{a.data(), b.data(), cc.data(), candPos.data(), pi.data(), cByPi.data(), keep.data(), posToCand.data(), scal.data(), tmp.data()};
-    return ot_distribute(s, keys, nodeOf.data(), nk, W, H, nIni, hX, N, out, cap);
+    OtMemKeys ks{keys, nodeOf.data(), nk};
+    (void)W;
+    return ot_distribute(s, ks, keys, H, nIni, hX, N, out, cap);
 }

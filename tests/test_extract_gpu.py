@@ -130,7 +130,7 @@ def test_octree_standalone_random(vsa, oracle):
         W = int(rng.integers(80, 1300)); H = int(rng.integers(80, 500))
         if round(W / H) < 1:
             continue
-        n = int(rng.integers(0, 6000 if it % 4 == 0 else 500))
+        n = int(rng.integers(0, (40000 if it % 8 == 0 else 6000) if it % 4 == 0 else 500))
         N = int(rng.integers(0, 400)) if it % 7 else 1500
         pts = set()
         cx, cy = int(rng.integers(3, W - 3)), int(rng.integers(3, H - 3))
@@ -146,6 +146,7 @@ def test_octree_standalone_random(vsa, oracle):
         s = rng.integers(7, 12 if it % 2 else 200, len(pts)).astype(np.uint8)
         keys = vsa.pack_keys(x, y, s)
         sel = oracle.distribute_octree(x, y, s, 16, 16 + W, 16, 16 + H, N)
-        got = vsa.distribute_octree(keys, 16, 16 + W, 16, 16 + H, N, device=0)
-        assert len(got) == len(sel), (it, W, H, len(pts), N)
-        assert np.array_equal(got, keys[sel]), (it, W, H, len(pts), N)
+        for storage in ((0, 1) if it % 5 == 0 else (0,)):     # keys in registers (default) / in device memory
+            got = vsa.distribute_octree(keys, 16, 16 + W, 16, 16 + H, N, device=0, key_storage=storage)
+            assert len(got) == len(sel), (it, W, H, len(pts), N, storage)
+            assert np.array_equal(got, keys[sel]), (it, W, H, len(pts), N, storage)

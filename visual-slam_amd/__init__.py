@@ -65,6 +65,7 @@ _SIGS = {
     "orbx_debug_candidates": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "orbx_debug_level_keypoints": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "orbx_distribute_octree": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, C.POINTER(_i)]),
+    "orbx_distribute_octree_ex": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, C.POINTER(_i), _i]),
     "orbx_extractor_set_profiling": (_i, [_vp, _i]),
     "orbx_extractor_stage_ms": (_i, [_vp, _vp]),
     "orbx_matcher_create": (_i, [_i, C.POINTER(_vp)]),
@@ -190,12 +191,12 @@ def pack_keys(x, y, s):
     return ((np.asarray(x, np.uint32) << 20) | (np.asarray(y, np.uint32) << 8) | np.asarray(s, np.uint32)).astype(np.uint32)
 
 
-def distribute_octree(packed, minX, maxX, minY, maxY, N, device=-1):
+def distribute_octree(packed, minX, maxX, minY, maxY, N, device=-1, key_storage=0):
     packed = np.ascontiguousarray(packed, np.uint32)
     cap = max(N + 16, 4 * 64 + 16)
     out = np.zeros(cap, np.uint32)
     n = C.c_int()
-    _check(lib.orbx_distribute_octree(device, _ptr(packed), len(packed), minX, maxX, minY, maxY, N, _ptr(out), cap, C.byref(n)))
+    _check(lib.orbx_distribute_octree_ex(device, _ptr(packed), len(packed), minX, maxX, minY, maxY, N, _ptr(out), cap, C.byref(n), key_storage))
     return out[:n.value]
 
 

@@ -25,6 +25,7 @@
 static inline int ot_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned ot_atomic_max(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline float ot_fdiv(float a, float b) { return a / b; }
+static inline void ot_count(int* base, int idx) { base[idx] += 1; }
 #else
 #define OT_DEV __device__ __forceinline__
 #define OT_TID ((int)threadIdx.x)
@@ -33,6 +34,25 @@ static inline float ot_fdiv(float a, float b) { return a / b; }
 static __device__ __forceinline__ int ot_atomic_add(int* p, int v) { return atomicAdd(p, v); }
 static __device__ __forceinline__ unsigned ot_atomic_max(unsigned* p, unsigned v) { return atomicMax(p, v); }
 static __device__ __forceinline__ float ot_fdiv(float a, float b) { return __fdiv_rn(a, b); }
+// base[idx] += 1 from every calling lane.  Neighbouring keys mostly fall into the same node and quadrant, so
+// the lanes of a wave are first grouped by target (up to four groups, one LDS atomic each); what is left
+// adds on its own.  Without this the LDS serialises up to 64 same-address atomics per wave instruction.
+static __device__ __forceinline__ void ot_count(int* base, int idx)
+{
+    const int lane = threadIdx.x & 63;
+    bool pending = true;
+    for (int r = 0; r < 4; ++r) {
+        const unsigned long long todo = __ballot(pending);
+        if (!todo) return;
+        const int leader = __ffsll((long long)todo) - 1;
+        const int t = __shfl(idx, leader, 64);
+        const bool mine = pending && idx == t;
+        const unsigned long long same = __ballot(mine);
+        if (lane == leader) atomicAdd(&base[t], __popcll(same));
+        if (mine) pending = false;
+    }
+    if (pending) atomicAdd(&base[idx], 1);
+}
 #endif
 
 namespace orbx {
@@ -70,6 +90,21 @@ static OT_DEV int ot_block_scan(int32_t* a, int n, int32_t* tmp)
     return run;
 #else
     const int tid = OT_TID, nt = OT_NT;
+    if (n <= nt) {
+        // one element per thread: wave-level scan, then the totals of the waves in front
+        const int lane1 = tid & 63, wave1 = tid >> 6;
+        const int v = tid < n ? a[tid] : 0;
+        int inc1 = v;
+        for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc1, d, 64); if (lane1 >= d) inc1 += o; }
+        if (lane1 == 63) tmp[wave1] = inc1;
+        __syncthreads();
+        const int nw1 = (nt + 63) >> 6;
+        int base1 = 0, total1 = 0;
+        for (int w = 0; w < nw1; ++w) { const int t = tmp[w]; total1 += t; if (w < wave1) base1 += t; }
+        if (tid < n) a[tid] = base1 + inc1 - v;
+        __syncthreads();
+        return total1;
+    }
     const int chunk = (n + nt - 1) / nt;
     const int b = tid * chunk, e = min(b + chunk, n);
     int sum = 0;
@@ -114,10 +149,115 @@ static OT_DEV void ot_child_box(const OtNode& p, int q, OtNode& c)
     c.y1 = (int16_t)((q & 2) ? p.y1 : my);
 }
 
+// Key storage.  Thread tid owns the keys tid, tid+nt, tid+2nt, ... ("slot" j = key tid + j*nt) for the whole
+// run, and only the owner ever touches a key's node id.  The arrays live in LDS when a level's keys fit
+// there and in device memory otherwise.
+struct OtMemKeys {
+    const uint32_t* keys; uint16_t* node; int nk;
+    OT_DEV uint32_t key(int, int k) const { return keys[k]; }
+    OT_DEV uint16_t get(int, int k) const { return node[k]; }
+    OT_DEV void set(int, int k, uint16_t v) { node[k] = v; }
+};
+// f(slot, key index) for every key the calling thread owns
+template <class KS, class F>
+static OT_DEV void ot_for_keys(KS& ks, int tid, int nt, F&& f)
+{
+    int j = 0;
+    for (int k = tid; k < ks.nk; k += nt, ++j) f(j, k);
+}
+
+// Two-phase form: `look` (loads only, returns a value) runs for four keys before `commit` (stores, atomics)
+// runs for them, so the four dependent load chains overlap instead of running back to back.
+template <class KS, class L, class C>
+static OT_DEV void ot_for_keys4(KS& ks, int tid, int nt, L&& look, C&& commit)
+{
+    int j = 0;
+    for (int k = tid; k < ks.nk; k += 4 * nt, j += 4) {
+        auto v0 = look(j, k);
+        const int k1 = k + nt, k2 = k + 2 * nt, k3 = k + 3 * nt;
+        decltype(v0) v1 = v0, v2 = v0, v3 = v0;
+        if (k1 < ks.nk) v1 = look(j + 1, k1);
+        if (k2 < ks.nk) v2 = look(j + 2, k2);
+        if (k3 < ks.nk) v3 = look(j + 3, k3);
+        commit(j, k, v0);
+        if (k1 < ks.nk) commit(j + 1, k1, v1);
+        if (k2 < ks.nk) commit(j + 2, k2, v2);
+        if (k3 < ks.nk) commit(j + 3, k3, v3);
+    }
+}
+
+// Coarse sweep (:605-664): every node with more than one key is split, in list order.  One packed prefix sum
+// (children in the low half, unsplit nodes in the high half) places everything.
+template <class KS>
+static OT_DEV void ot_coarse_step(OtShared& s, KS& ks)
+{
+    const int tid = OT_TID, nt = OT_NT;
+    const int n = s.scal[OT_N];
+    for (int i = tid; i < 4 * n; i += nt) s.cc[i] = 0;
+    if (tid == 0) s.scal[OT_NEXP] = 0;
+    OT_SYNC();
+    ot_for_keys4(ks, tid, nt,
+        [&](int j, int k) -> int {
+            const uint16_t p = ks.get(j, k);
+            return p == kOtDead ? -1 : 4 * p + ot_quadrant(s.cur[p], ks.key(j, k));
+        },
+        [&](int, int, int target) { if (target >= 0) ot_count(s.cc, target); });
+    OT_SYNC();
+    for (int p = tid; p < n; p += nt) {
+        const int* c = &s.cc[4 * p];
+        s.keep[p] = s.cur[p].cnt > 1 ? (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) : (1 << 16);
+    }
+    OT_SYNC();
+    const int tot = ot_block_scan(s.keep, n, s.scanTmp);
+    const int C = tot & 0xFFFF, nkeep = tot >> 16;
+    const int seqBase = s.scal[OT_SEQ];
+    for (int p = tid; p < n; p += nt) {
+        const int cex = s.keep[p] & 0xFFFF, kex = s.keep[p] >> 16;
+        if (s.cur[p].cnt > 1) {
+            int* c = &s.cc[4 * p];
+            const int cn = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
+            const int bs = C - cex - cn;     // children of the node visited last come first
+            int before = 0, nexp = 0;
+            for (int q = 0; q < 4; ++q) {
+                const int cnt = c[q];
+                if (cnt > 0) {
+                    const int np = bs + (cn - 1 - before);   // n4 sits at the front of the block
+                    OtNode ch;
+                    ot_child_box(s.cur[p], q, ch);
+                    ch.cnt = cnt;
+                    ch.aux = (uint32_t)(seqBase + cex + before);
+                    s.nxt[np] = ch;
+                    c[q] = np;
+                    nexp += cnt > 1;
+                    ++before;
+                } else c[q] = -1;
+            }
+            if (nexp) ot_atomic_add(&s.scal[OT_NEXP], nexp);
+        } else {
+            s.nxt[C + kex] = s.cur[p];       // nodes with one key keep their relative order at the back
+        }
+    }
+    OT_SYNC();
+    ot_for_keys4(ks, tid, nt,
+        [&](int j, int k) -> int {
+            const uint16_t p = ks.get(j, k);
+            if (p == kOtDead) return -1;
+            const int np = s.cc[4 * p + ot_quadrant(s.cur[p], ks.key(j, k))];
+            return s.nxt[np].cnt == 1 ? np | (1 << 30) : np;
+        },
+        [&](int j, int k, int np) {
+            if (np < 0) return;
+            if (np & (1 << 30)) { s.nxt[np & 0xFFFF].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
+            else ks.set(j, k, (uint16_t)np);
+        });
+    if (tid == 0) { s.scal[OT_N] = C + nkeep; s.scal[OT_SEQ] = seqBase + C; }
+    OT_SYNC();
+}
+
 // One split step.  fine == 0: coarse sweep; fine == 1: sorted pass with the cut at N.
-// keys / nodeOf: global arrays of nk entries.  Returns nothing; updates s.scal[OT_N], OT_NEXP, OT_SEQ
-// and swaps the roles of cur/nxt through the caller (the caller swaps pointers after the call).
-static OT_DEV void ot_split_step(OtShared& s, const uint32_t* keys, uint16_t* nodeOf, int nk, int N, int fine)
+// Updates s.scal[OT_N], OT_NEXP, OT_SEQ; the caller swaps cur/nxt after the call.
+template <class KS>
+static OT_DEV void ot_split_step(OtShared& s, KS& ks, int N, int fine)
 {
     const int tid = OT_TID, nt = OT_NT;
     const int n = s.scal[OT_N];
@@ -133,12 +273,12 @@ static OT_DEV void ot_split_step(OtShared& s, const uint32_t* keys, uint16_t* no
     }
     OT_SYNC();
     // child key counts of every candidate
-    for (int k = tid; k < nk; k += nt) {
-        const uint16_t p = nodeOf[k];
-        if (p == kOtDead) continue;
+    ot_for_keys(ks, tid, nt, [&](int j, int k) {
+        const uint16_t p = ks.get(j, k);
+        if (p == kOtDead) return;
         const int e = s.posToCand[p];
-        ot_atomic_add(&s.cc[4 * e + ot_quadrant(s.cur[p], keys[k])], 1);
-    }
+        ot_count(s.cc, 4 * e + ot_quadrant(s.cur[p], ks.key(j, k)));
+    });
     OT_SYNC();
     // processing order
     if (!fine) {
@@ -147,12 +287,17 @@ static OT_DEV void ot_split_step(OtShared& s, const uint32_t* keys, uint16_t* no
         OT_SYNC();
     } else {
         // rank by (count desc, sequence desc): the reference sorts ascending and walks from the back (:683-684)
+        // (compact copies of count and sequence first, so the inner loop has no dependent loads)
+        for (int e = tid; e < E; e += nt) { const OtNode& a = s.cur[s.candPos[e]]; s.cByPi[e] = a.cnt; s.keep[e] = (int32_t)a.aux; }
+        OT_SYNC();
         for (int e = tid; e < E; e += nt) {
-            const OtNode& a = s.cur[s.candPos[e]];
+            const int acnt = s.cByPi[e];
+            const uint32_t aseq = (uint32_t)s.keep[e];
             int r = 0;
             for (int m = 0; m < E; ++m) {
-                const OtNode& b = s.cur[s.candPos[m]];
-                r += (b.cnt > a.cnt) || (b.cnt == a.cnt && b.aux > a.aux);
+                const int bcnt = s.cByPi[m];
+                const uint32_t bseq = (uint32_t)s.keep[m];
+                r += (bcnt > acnt) || (bcnt == acnt && bseq > aseq);
             }
             s.pi[e] = r;
         }
@@ -231,17 +376,17 @@ static OT_DEV void ot_split_step(OtShared& s, const uint32_t* keys, uint16_t* no
     }
     OT_SYNC();
     // keys follow their nodes
-    for (int k = tid; k < nk; k += nt) {
-        const uint16_t p = nodeOf[k];
-        if (p == kOtDead) continue;
+    ot_for_keys(ks, tid, nt, [&](int j, int k) {
+        const uint16_t p = ks.get(j, k);
+        if (p == kOtDead) return;
         const int e = s.posToCand[p];
         if (s.pi[e] <= rstar) {
-            const uint32_t key = keys[k];
+            const uint32_t key = ks.key(j, k);
             const int np = s.cc[4 * e + ot_quadrant(s.cur[p], key)];
-            if (s.nxt[np].cnt == 1) { s.nxt[np].aux = key; nodeOf[k] = kOtDead; }
-            else nodeOf[k] = (uint16_t)np;
-        } else nodeOf[k] = (uint16_t)s.keep[p];
-    }
+            if (s.nxt[np].cnt == 1) { s.nxt[np].aux = key; ks.set(j, k, kOtDead); }
+            else ks.set(j, k, (uint16_t)np);
+        } else ks.set(j, k, (uint16_t)s.keep[p]);
+    });
     OT_SYNC();
     if (tid == 0) {
         s.scal[OT_N] = C + (n - nsplit);
@@ -251,11 +396,13 @@ static OT_DEV void ot_split_step(OtShared& s, const uint32_t* keys, uint16_t* no
     OT_SYNC();
 }
 
-// Whole DistributeOctTree for one key set.  keys: packed x<<20|y<<8|score (coordinates relative to
-// minBorder), nodeOf: scratch of nk uint16, W/H: maxX-minX / maxY-minY, nIni/hX: roots (:542-544).
-// out receives the selected keys in list order; returns their number (all threads).
-static OT_DEV int ot_distribute(OtShared& s, const uint32_t* keys, uint16_t* nodeOf, int nk,
-                                int W, int H, int nIni, float hX, int N, uint32_t* out, int outCap)
+// Whole DistributeOctTree for one key set held by the key store ks (keys packed x<<20|y<<8|score,
+// coordinates relative to minBorder; keys: the same keys in memory, read at the end for the winners).
+// H: maxY-minY, nIni/hX: roots (:542-544).  out receives the selected keys in list order; returns their
+// number (all threads).
+template <class KS>
+static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
+                                int H, int nIni, float hX, int N, uint32_t* out, int outCap)
 {
     const int tid = OT_TID, nt = OT_NT;
     // roots (:551-569)
@@ -266,37 +413,37 @@ static OT_DEV int ot_distribute(OtShared& s, const uint32_t* keys, uint16_t* nod
         r.y0 = 0; r.y1 = (int16_t)H;
         r.cnt = 0; r.aux = (uint32_t)i;
         s.nxt[i] = r;
+        s.cc[i] = 0;
     }
     if (tid == 0) { s.scal[OT_SEQ] = nIni; }
     OT_SYNC();
-    for (int k = tid; k < nk; k += nt) {
-        int r = (int)ot_fdiv((float)ot_key_x(keys[k]), hX);
+    ot_for_keys(ks, tid, nt, [&](int j, int k) {
+        int r = (int)ot_fdiv((float)ot_key_x(ks.key(j, k)), hX);
         if (r > nIni - 1) r = nIni - 1;
-        nodeOf[k] = (uint16_t)r;
-        ot_atomic_add(&s.nxt[r].cnt, 1);
-    }
+        ks.set(j, k, (uint16_t)r);
+        ot_count(s.cc, r);
+    });
     OT_SYNC();
     // drop empty roots (:571-584); a root with one key keeps it
-    for (int i = tid; i < nIni; i += nt) s.keep[i] = s.nxt[i].cnt > 0 ? 1 : 0;
+    for (int i = tid; i < nIni; i += nt) { s.nxt[i].cnt = s.cc[i]; s.keep[i] = s.cc[i] > 0 ? 1 : 0; }
     OT_SYNC();
     const int n0 = ot_block_scan(s.keep, nIni, s.scanTmp);
     for (int i = tid; i < nIni; i += nt) if (s.nxt[i].cnt > 0) s.cur[s.keep[i]] = s.nxt[i];
     OT_SYNC();
-    for (int k = tid; k < nk; k += nt) {
-        const int np = s.keep[nodeOf[k]];
-        if (s.cur[np].cnt == 1) { s.cur[np].aux = keys[k]; nodeOf[k] = kOtDead; }
-        else nodeOf[k] = (uint16_t)np;
-    }
+    ot_for_keys(ks, tid, nt, [&](int j, int k) {
+        const int np = s.keep[ks.get(j, k)];
+        if (s.cur[np].cnt == 1) { s.cur[np].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
+        else ks.set(j, k, (uint16_t)np);
+    });
     if (tid == 0) s.scal[OT_N] = n0;
     OT_SYNC();
-    (void)W;
 
     // main loop (:593-738)
     bool finish = false;
     while (!finish) {
         const int prevSize = s.scal[OT_N];
         OT_SYNC();
-        ot_split_step(s, keys, nodeOf, nk, N, 0);
+        ot_coarse_step(s, ks);
         { OtNode* t = s.cur; s.cur = s.nxt; s.nxt = t; }
         const int n = s.scal[OT_N], nToExpand = s.scal[OT_NEXP];
         if (n >= N || n == prevSize) finish = true;
@@ -304,7 +451,7 @@ static OT_DEV int ot_distribute(OtShared& s, const uint32_t* keys, uint16_t* nod
             while (!finish) {
                 const int prev2 = s.scal[OT_N];
                 OT_SYNC();
-                ot_split_step(s, keys, nodeOf, nk, N, 1);
+                ot_split_step(s, ks, N, 1);
                 { OtNode* t = s.cur; s.cur = s.nxt; s.nxt = t; }
                 const int n2 = s.scal[OT_N];
                 if (n2 >= N || n2 == prev2) finish = true;
@@ -317,11 +464,11 @@ static OT_DEV int ot_distribute(OtShared& s, const uint32_t* keys, uint16_t* nod
     unsigned* best = reinterpret_cast<unsigned*>(s.keep);
     for (int p = tid; p < n; p += nt) best[p] = 0;
     OT_SYNC();
-    for (int k = tid; k < nk; k += nt) {
-        const uint16_t p = nodeOf[k];
-        if (p == kOtDead) continue;
-        ot_atomic_max(&best[p], ((keys[k] & 0xFFu) << 24) | (0xFFFFFFu - (unsigned)k));
-    }
+    ot_for_keys(ks, tid, nt, [&](int j, int k) {
+        const uint16_t p = ks.get(j, k);
+        if (p == kOtDead) return;
+        ot_atomic_max(&best[p], ((ks.key(j, k) & 0xFFu) << 24) | (0xFFFFFFu - (unsigned)k));
+    });
     OT_SYNC();
     for (int p = tid; p < n && p < outCap; p += nt) {
         const OtNode& nd = s.cur[p];

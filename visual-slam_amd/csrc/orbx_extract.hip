@@ -9,6 +9,7 @@
 //   k_describe    IC angle, 7x7 Gaussian on the patch, rBRIEF, output record  :76-146, :1084-1102
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <vector>
@@ -449,7 +450,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 constexpr int kOctThreads = 256;
 
-__device__ void ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads)
+// LDS layout: the node tables of OtShared (capacity NC nodes), then room for KL keys (4 B) and node ids (2 B)
+__device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads)
 {
     size_t o = 0;
     s.cur = reinterpret_cast<OtNode*>(mem + o); o += sizeof(OtNode) * NC;
@@ -462,10 +464,13 @@ __device__ void ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads)
     s.posToCand = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * NC;
     s.scal = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * 16;
     s.scanTmp = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * (nthreads / 64 + 2);
+    return (o + 15) & ~(size_t)15;
 }
-size_t ot_lds_bytes(int NC, int nthreads)
+size_t ot_lds_bytes(int NC, int nthreads, int KL)
 {
-    return sizeof(OtNode) * 2 * NC + sizeof(int32_t) * (4 + 5) * NC + sizeof(int32_t) * 16 + sizeof(int32_t) * (nthreads / 64 + 2);
+    size_t o = sizeof(OtNode) * 2 * NC + sizeof(int32_t) * (4 + 5) * NC + sizeof(int32_t) * 16 + sizeof(int32_t) * (nthreads / 64 + 2);
+    o = (o + 15) & ~(size_t)15;
+    return o + (size_t)KL * 6 + 16;
 }
 
 __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
@@ -473,56 +478,79 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
                                                         const uint16_t* __restrict__ cellcnt, int ncells,
                                                         uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int key_total,
                                                         uint32_t* __restrict__ lvlkp, int kp_total,
-                                                        int32_t* __restrict__ lvlcnt, int nlevels, int NCmax)
+                                                        int32_t* __restrict__ lvlcnt, int nlevels, int NCmax, int KL)
 {
     extern __shared__ __align__(16) unsigned char ot_mem[];
     __shared__ int s_nk;
     const int tid = threadIdx.x;
-    const int level = blockIdx.x, frame = blockIdx.y;
+    const int level = blockIdx.y, frame = blockIdx.x;
     const DevLevel& L = lv[level];
     OtShared s;
-    ot_carve(s, ot_mem, NCmax, kOctThreads);
+    const int NT = blockDim.x;
+    const size_t keyOff = ot_carve(s, ot_mem, NCmax, kOctThreads);
 
-    // gather: exclusive scan of the cell counts in chunks, then copy each cell's slots
-    uint32_t* K = keys + (unsigned long long)frame * key_total + L.key_offset;
-    uint16_t* NO = nodeOf + (unsigned long long)frame * key_total + L.key_offset;
     const uint16_t* cnt = cellcnt + (unsigned long long)frame * ncells + L.cell_first;
     const uint32_t* slots = cand + (unsigned long long)frame * cand_total + L.cand_offset;
+    // number of candidates of this level: decides where the key arrays live
+    int part = 0;
+    for (int i = tid; i < L.cell_count; i += NT) part += cnt[i];
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     if (tid == 0) s_nk = 0;
     __syncthreads();
+    if ((tid & 63) == 0) atomicAdd(&s_nk, part);
+    __syncthreads();
+    const int nk = s_nk;
+    uint32_t* K; uint16_t* NO;
+    if (nk <= KL) {
+        K = reinterpret_cast<uint32_t*>(ot_mem + keyOff);
+        NO = reinterpret_cast<uint16_t*>(ot_mem + keyOff + (size_t)KL * 4);
+    } else {
+        K = keys + (unsigned long long)frame * key_total + L.key_offset;
+        NO = nodeOf + (unsigned long long)frame * key_total + L.key_offset;
+    }
+    // gather the per-cell slots into one dense array (cell-row-major, raster inside a cell)
+    int base = 0;
     for (int c0 = 0; c0 < L.cell_count; c0 += NCmax) {
         const int m = min(NCmax, L.cell_count - c0);
-        for (int i = tid; i < m; i += kOctThreads) s.keep[i] = cnt[c0 + i];
+        for (int i = tid; i < m; i += NT) s.keep[i] = cnt[c0 + i];
         __syncthreads();
         const int tot = ot_block_scan(s.keep, m, s.scanTmp);
-        const int base = s_nk;
-        for (int i = tid; i < m; i += kOctThreads) {
+        for (int i = tid; i < m; i += NT) {
             const CellRec& cr = cells[L.cell_first + c0 + i];
             const int n = cnt[c0 + i];
             const int o = base + s.keep[i];
             for (int j = 0; j < n; ++j) K[o + j] = slots[cr.slot + j];
         }
         __syncthreads();
-        if (tid == 0) s_nk = base + tot;
-        __syncthreads();
+        base += tot;
     }
-    const int nk = s_nk;
     __threadfence_block();
     __syncthreads();
     uint32_t* out = lvlkp + (unsigned long long)frame * kp_total + L.kp_offset;
-    const int n = ot_distribute(s, K, NO, nk, L.maxBorderX - kMinBorder, L.maxBorderY - kMinBorder, L.nIni, L.hX, L.quota, out, L.kp_cap);
+    OtMemKeys ks{K, NO, nk};
+    const int n = ot_distribute(s, ks, K, L.maxBorderY - kMinBorder, L.nIni, L.hX, L.quota, out, L.kp_cap);
     if (tid == 0) lvlcnt[frame * nlevels + level] = min(n, L.kp_cap);
 }
 
 // standalone form for parity tests: keys already dense
 __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int nk,
                                                                int W, int H, int nIni, float hX, int N,
-                                                               uint32_t* __restrict__ out, int outCap, int32_t* __restrict__ nOut, int NC)
+                                                               uint32_t* __restrict__ out, int outCap, int32_t* __restrict__ nOut, int NC,
+                                                               int KL)
 {
     extern __shared__ __align__(16) unsigned char ot_mem[];
     OtShared s;
-    ot_carve(s, ot_mem, NC, kOctThreads);
-    const int n = ot_distribute(s, keys, nodeOf, nk, W, H, nIni, hX, N, out, outCap);
+    const size_t keyOff = ot_carve(s, ot_mem, NC, kOctThreads);
+    const uint32_t* K = keys; uint16_t* NO = nodeOf;
+    if (nk <= KL) {                     // KL == 0 keeps the keys in device memory
+        uint32_t* kl = reinterpret_cast<uint32_t*>(ot_mem + keyOff);
+        for (int k = threadIdx.x; k < nk; k += kOctThreads) kl[k] = keys[k];
+        K = kl;
+        NO = reinterpret_cast<uint16_t*>(ot_mem + keyOff + (size_t)KL * 4);
+        __syncthreads();
+    }
+    OtMemKeys ks{K, NO, nk};
+    const int n = ot_distribute(s, ks, K, H, nIni, hX, N, out, outCap);
     if (threadIdx.x == 0) *nOut = n;
 }
 
@@ -774,6 +802,8 @@ struct orbx_extractor {
     int key_total = 0;
     int max_border_threads = 0;
     int NCmax = 0;
+    int KL = 0;              // keys of one level that fit the quadtree's LDS key arrays
+    int oct_threads = kOctThreads;
     size_t oct_lds = 0;
     int last_frames = 0;
     bool profiling = false;
@@ -827,7 +857,16 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     }
     ex->key_total = key_off;
     ex->NCmax = std::max(ncmax + 8, 64);
-    ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads);
+    ex->KL = std::min(8192, std::max(2048, (width * height) / 64));
+    {
+        // large quotas leave less LDS for keys; below 512 keys the LDS arrays are not worth having
+        const long room = 150L * 1024 - (long)ot_lds_bytes(ex->NCmax, kOctThreads, 0) - 64;
+        ex->KL = (int)std::max(0L, std::min((long)ex->KL, room / 6));
+        if (ex->KL < 512) ex->KL = 0;
+    }
+    if (const char* e = getenv("ORBX_OCT_THREADS")) ex->oct_threads = std::max(64, std::min(kOctThreads, atoi(e) / 64 * 64));
+    if (const char* e = getenv("ORBX_OCT_KL")) ex->KL = atoi(e);
+    ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads, ex->KL);
     if (ex->oct_lds > 150 * 1024) { delete ex; set_error("per-level keypoint quota too large for the quadtree working set in LDS"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ex->oct_lds));
     HIP_CHECK(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
@@ -916,10 +955,12 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
     {
-        dim3 grid(G.nlevels, B);
-        hipLaunchKernelGGL(k_octree, grid, dim3(kOctThreads), ex->oct_lds, st, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total,
+        // frame is the fast grid index: consecutive workgroups go to different XCDs, so every XCD gets an equal
+        // share of each level (a level-major order would put all level-0 quadtrees, the largest, on one XCD)
+        dim3 grid(B, G.nlevels);
+        hipLaunchKernelGGL(k_octree, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total,
                            ex->d_cellcnt, (int)G.cells.size(), ex->d_keys, ex->d_nodeof, ex->key_total, ex->d_lvlkp,
-                           G.kp_total, ex->d_lvlcnt, G.nlevels, ex->NCmax);
+                           G.kp_total, ex->d_lvlcnt, G.nlevels, ex->NCmax, ex->KL);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
     {
@@ -1055,13 +1096,20 @@ int orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, uint32_
 int orbx_distribute_octree(int device, const uint32_t* packed_keys, int n, int minX, int maxX, int minY, int maxY, int N,
                            uint32_t* out, int cap, int* n_out)
 {
+    return orbx_distribute_octree_ex(device, packed_keys, n, minX, maxX, minY, maxY, N, out, cap, n_out, 0);
+}
+
+int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, int minX, int maxX, int minY, int maxY, int N,
+                              uint32_t* out, int cap, int* n_out, int key_storage)
+{
     if (!n_out || n < 0 || (n > 0 && !packed_keys) || maxX <= minX || maxY <= minY || N < 0 || n >= (1 << 24)) { set_error("orbx_distribute_octree: bad argument"); return ORBX_ERR_BAD_ARG; }
     const int W = maxX - minX, H = maxY - minY;
     const int nIni = (int)std::round((float)W / H);
     if (nIni <= 0 || nIni > kMaxRoots || W >= 4096 || H >= 4096) { set_error("orbx_distribute_octree: unsupported box"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     const float hX = (float)W / nIni;
     const int NC = std::max(std::max(N + 3, 4 * nIni) + 9, 64);
-    const size_t lds = ot_lds_bytes(NC, kOctThreads);
+    const int KL = key_storage == 0 ? 4096 : 0;
+    const size_t lds = ot_lds_bytes(NC, kOctThreads, KL);
     if (lds > 150 * 1024) { set_error("N too large for the quadtree working set in LDS"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     int rc = select_device(device);
     if (rc) return rc;
@@ -1072,7 +1120,7 @@ int orbx_distribute_octree(int device, const uint32_t* packed_keys, int n, int m
     HIP_CHECK(hipMalloc(&d_n, sizeof(int32_t)));
     if (n) HIP_CHECK(hipMemcpy(d_keys, packed_keys, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree_single), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(kOctThreads), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC);
+    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(kOctThreads), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL);
     HIP_CHECK(hipGetLastError());
     int32_t cnt = 0;
     HIP_CHECK(hipMemcpy(&cnt, d_n, sizeof(int32_t), hipMemcpyDeviceToHost));
