@@ -91,8 +91,9 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
 /* mvImagePyramid[level] of frame `frame` of the last batch (include/ORBextractor.h:150): the padded
  * (w+38) x (h+38) buffer is copied to dst (host); the image ROI starts at row 19, column 19. */
 int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride);
-/* Device view of the same level: pointer to the ROI origin and its row stride (border readable at
- * negative offsets down to -19). */
+/* Device view of the same level: pointer to the ROI origin and its row stride.  The batch path fills the
+ * 3 innermost pixels of the REFLECT_101 frame (all any stage reads); orbx_pyramid_level completes the
+ * 19-pixel frame of the level it copies. */
 int orbx_pyramid_level_device(orbx_extractor* ex, int frame, int level, const uint8_t** d_roi,
                               int* w, int* h, ptrdiff_t* stride);
 
@@ -101,6 +102,10 @@ int orbx_pyramid_level_device(orbx_extractor* ex, int frame, int level, const ui
 int orbx_debug_candidates(orbx_extractor* ex, int frame, int level, uint32_t* packed, int cap, int* n);
 /* Keypoints chosen by DistributeOctTree for one level, list order, same packing. */
 int orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, uint32_t* packed, int cap, int* n);
+
+/* GaussianBlur(7x7, sigma 2) of one level of the last batch (the workingMat of src/ORBextractor.cc:1084-1085),
+ * w x h pixels copied to dst (host). */
+int orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride);
 
 /* DistributeOctTree on its own (src/ORBextractor.cc:538-762): host arrays in, device kernel, host out.
  * keys packed as above; out receives the selected keys in list order. */

@@ -41,6 +41,9 @@ def test_stage_parity(vsa, oracle, cfg):
         assert got.shape == want.shape, l
         assert np.array_equal(got, want), f"pyramid level {l}: {np.count_nonzero(got != want)} pixels differ"
     for l in range(nl):
+        got, want = ex.debug_blurred_level(0, l), oex.level_blurred(l)
+        assert want is None or np.array_equal(got, want), f"blurred level {l}: {np.count_nonzero(got != want)} pixels differ"
+    for l in range(nl):
         gx, gy, gs = vsa.unpack_keys(ex.debug_candidates(0, l))
         ox, oy, os_ = oex.level_candidates(l)
         assert len(gx) == len(ox), f"level {l}: {len(gx)} candidates vs {len(ox)}"
@@ -65,8 +68,12 @@ def test_stage_parity(vsa, oracle, cfg):
 
 def test_blur_rounding_simd_mode(vsa, oracle):
     cfg = (640, 480, 1000, 8, 1.2, 20, 7, 11)
-    *_, kps, desc, okps, odesc = run_both(vsa, oracle, cfg, blur_rounding=1)
+    _, ex, oex, kps, desc, okps, odesc = run_both(vsa, oracle, cfg, blur_rounding=1)
+    for l in range(8):
+        got, want = ex.debug_blurred_level(0, l), oex.level_blurred(l)
+        assert want is not None and np.array_equal(got, want), f"blurred level {l}"
     assert np.array_equal(kps["x"], okps["x"]) and np.array_equal(desc, odesc)
+    ex.close()
 
 
 def test_batch_matches_single(vsa, oracle):

@@ -62,6 +62,7 @@ _SIGS = {
     "orbx_extract_batch_device": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i, _vp]),
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _pd]),
     "orbx_pyramid_level_device": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd)]),
+    "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _pd]),
     "orbx_debug_candidates": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "orbx_debug_level_keypoints": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "orbx_distribute_octree": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, C.POINTER(_i)]),
@@ -243,6 +244,12 @@ class Extractor:
         w, h = level_size(self.params, self.width, self.height, level)
         out = np.zeros((h + 38, w + 38), np.uint8)
         _check(lib.orbx_pyramid_level(self.h, frame, level, _ptr(out), out.strides[0]))
+        return out
+
+    def debug_blurred_level(self, frame, level):
+        w, h = level_size(self.params, self.width, self.height, level)
+        out = np.zeros((h, w), np.uint8)
+        _check(lib.orbx_debug_blurred_level(self.h, frame, level, _ptr(out), out.strides[0]))
         return out
 
     def debug_candidates(self, frame, level):

@@ -6,7 +6,8 @@
 //   k_resize x(L-1)  fixed-point bilinear + border, level l from l-1  ComputePyramid :1117-1123
 //   k_fast_cells  per-cell FAST-9 score, NMS, threshold fallback   ComputeKeyPointsOctTree :788-828
 //   k_octree      quadtree selection, one workgroup per level      DistributeOctTree :538-762
-//   k_describe    IC angle, 7x7 Gaussian on the patch, rBRIEF, output record  :76-146, :1084-1102
+//   k_blur        7x7 Gaussian of every level                      :1084-1085
+//   k_describe    IC angle, rBRIEF on the blurred level, output record  :76-146, :1086-1102
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -48,10 +49,6 @@ struct DevLevel {
     unsigned cpr_magic; // ceil(2^32 / cpr): row of flat chunk index i is umulhi(i, cpr_magic)
     int border_threads; // threads of k_borders for this level
     int pad;
-};
-
-__device__ __constant__ signed char c_pattern[1024] = {
-#include "../../include/orbx_pattern.inc"
 };
 
 typedef unsigned short us16x2 __attribute__((ext_vector_type(2)));
@@ -186,27 +183,38 @@ __global__ __launch_bounds__(256) void k_resize_generic(uint8_t* __restrict__ py
 }
 
 // REFLECT_101 frames of every level (cv::copyMakeBorder, src/ORBextractor.cc:1121-1127).  One thread per
-// dword of the frame area: all dwords of the 19 top and 19 bottom rows, and in the rows between them the
-// dwords left of the ROI (8) and from its right end to the end of the padded row.
-__global__ __launch_bounds__(256) void k_borders(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, const DevLevel* __restrict__ lv)
+// dword of the frame area: nb rows above and below the ROI, and in the rows between them ld dwords left of
+// the ROI and rd dwords from its right end.  No stage reads more than 3 pixels outside the ROI (the Gaussian
+// of a pixel at least 1 inside), so the batch path fills nb = 3, ld = 1, rd = 2; the full 19-pixel frame
+// (nb = 19, ld = 8, rd = to the end of the padded row) is filled when a padded level is asked for.
+__host__ __device__ inline int border_threads(int w, int h, int stride, int nb, int ld, int rdmax)
+{
+    const int rfirst = (kRoiX + w) >> 2;
+    const int rd = min(rdmax, (stride >> 2) - rfirst);
+    return 2 * nb * (rfirst + rd - (8 - ld)) + h * (ld + rd);
+}
+__global__ __launch_bounds__(256) void k_borders(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, const DevLevel* __restrict__ lv,
+                                                 int nb, int ld, int rdmax)
 {
     const DevLevel& L = lv[blockIdx.y];
-    const int dpr = L.stride >> 2;                       // dwords per padded row
     const int rfirst = (kRoiX + L.w) >> 2;               // first dword touching the right frame
-    const int side = 8 + (dpr - rfirst);                 // frame dwords of a middle row
-    const int nfull = 2 * kEdge * dpr;
+    const int rd = min(rdmax, (L.stride >> 2) - rfirst);
+    const int d0 = 8 - ld;                               // first dword of a full frame row
+    const int span = rfirst + rd - d0;
+    const int side = ld + rd;
+    const int nfull = 2 * nb * span;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nfull + L.h * side) return;
     int prow, d;
     if (i < nfull) {
-        const int r = i / dpr;
-        d = i - r * dpr;
-        prow = r < kEdge ? r : L.h + r;                  // rows 0..18 and h+19..h+37
+        const int r = i / span;
+        d = d0 + (i - r * span);
+        prow = r < nb ? kEdge - nb + r : kEdge + L.h + (r - nb);
     } else {
         const int j = i - nfull;
         const int r = j / side, k = j - r * side;
         prow = kEdge + r;
-        d = k < 8 ? k : rfirst + (k - 8);
+        d = k < ld ? d0 + k : rfirst + (k - ld);
     }
     uint8_t* base = pyr + (unsigned long long)blockIdx.z * pyr_bytes;
     const uint8_t* srow = base + L.roi + (long long)reflect101(prow - kEdge, L.h) * L.stride;
@@ -555,13 +563,85 @@ __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// Describe: one wavefront per selected keypoint.  The 43x43 neighbourhood is staged in LDS once and
-// serves the intensity centroid (radius 15, unblurred), the separable 7x7 Gaussian restricted to the
-// 37x37 window the rotated pattern can reach, and the 256 binary tests.
+// GaussianBlur 7x7 sigma 2 of every pyramid level (src/ORBextractor.cc:1084-1085): Q8 taps
+// 18,34,49,55,49,34,18 in both directions, one rounding (sum + 32768) >> 16 (cv::GaussianBlur's 8-bit
+// fixed-point path; with rounding mode 1 ties go to even for the columns an x86 SIMD row loop covers).
+// The reference blurs a clone of the level, so the filter's REFLECT_101 border is the pyramid's own frame.
+//
+// One thread owns 4 adjacent columns and slides down 16 rows: per input row three dwords are loaded, the
+// horizontal pass is two v_dot4_u32_u8 per pixel on byte-aligned windows (v_alignbyte_b32), horizontal sums
+// of two consecutive rows are packed into one dword per pixel, and the vertical pass is four
+// v_dot2_u32_u16 per output pixel over the last four row pairs.  No LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int kPatchW = 43, kPatchStride = 44, kBlurW = 37, kBlurStride = 40;
-constexpr int kHRows = 44;      // rows per column of the transposed horizontal-pass buffer (43 used, even for dword pairs)
-constexpr int kHCols = 40;      // columns written by the horizontal pass (37 used)
+constexpr int kBlurRows = 16;
+struct __attribute__((packed, aligned(4))) u96 { uint32_t a, b, c; };
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
+                                              const DevLevel* __restrict__ lv)
+{
+    const DevLevel& L = lv[blockIdx.y];
+    const int gpr = (L.w + 3) >> 2;
+    const int strips = (L.h + kBlurRows - 1) / kBlurRows;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= gpr * strips) return;
+    const int strip = i / gpr, g = i - strip * gpr;
+    const int y0 = strip * kBlurRows, x = 4 * g;
+    const unsigned long long fo = (unsigned long long)blockIdx.z * pyr_bytes + L.roi;
+    const uint8_t* src = pyr + fo + (long long)(y0 - 3) * L.stride + (x - 4);
+    uint8_t* dst = blr + fo + (long long)y0 * L.stride + x;
+    const bool even_ties = MODE != 0 && x < (L.w & ~3);
+    constexpr uint32_t T0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), T1 = 49u | (34u << 8) | (18u << 16);
+    constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
+    constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
+    uint32_t P[4][4];               // last four row pairs: per pixel, sums of rows 2j | 2j+1 << 16
+#pragma unroll
+    for (int j = 0; j < kBlurRows / 2 + 3; ++j) {
+        uint32_t h[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const u96 t = *reinterpret_cast<const u96*>(src + (long long)(2 * j + r) * L.stride);
+            h[r][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 1), T1,
+                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 1), T0, 0u, false), false);
+            h[r][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 2), T1,
+                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 2), T0, 0u, false), false);
+            h[r][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 3), T1,
+                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 3), T0, 0u, false), false);
+            h[r][3] = __builtin_amdgcn_udot4(t.c, T1, __builtin_amdgcn_udot4(t.b, T0, 0u, false), false);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) P[j & 3][k] = h[0][k] | (h[1][k] << 16);
+        if (j >= 3) {
+            const int m = j - 3;    // output rows 2m, 2m+1 of the strip: row pairs m .. m+3
+            uint32_t te[4], to[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#define ORBX_DOT2(a, w, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, (uint32_t)(a)), __builtin_bit_cast(us16x2, (uint32_t)(w)), acc, false)
+                const uint32_t d0 = P[m & 3][k], d1 = P[(m + 1) & 3][k], d2 = P[(m + 2) & 3][k], d3 = P[(m + 3) & 3][k];
+                const uint32_t se = ORBX_DOT2(d3, E3, ORBX_DOT2(d2, E2, ORBX_DOT2(d1, E1, ORBX_DOT2(d0, E0, 0u))));
+                const uint32_t so = ORBX_DOT2(d3, O3, ORBX_DOT2(d2, O2, ORBX_DOT2(d1, O1, ORBX_DOT2(d0, O0, 0u))));
+#undef ORBX_DOT2
+                te[k] = se + (even_ties ? 32767u + ((se >> 16) & 1u) : 32768u);
+                to[k] = so + (even_ties ? 32767u + ((so >> 16) & 1u) : 32768u);
+            }
+            // bits 16..24 of each sum hold the rounded value (at most 257): gather as 16-bit pairs, clamp, pack bytes
+            const us16x2 lim = {255, 255};
+            const uint32_t e01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[1], te[0], 0x07060302u)), lim));
+            const uint32_t e23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[3], te[2], 0x07060302u)), lim));
+            const uint32_t o01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[1], to[0], 0x07060302u)), lim));
+            const uint32_t o23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[3], to[2], 0x07060302u)), lim));
+            if (y0 + 2 * m < L.h) *reinterpret_cast<uint32_t*>(dst + (long long)(2 * m) * L.stride) = __builtin_amdgcn_perm(e23, e01, 0x06040200u);
+            if (y0 + 2 * m + 1 < L.h) *reinterpret_cast<uint32_t*>(dst + (long long)(2 * m + 1) * L.stride) = __builtin_amdgcn_perm(o23, o01, 0x06040200u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Describe: one wavefront per selected keypoint.  The intensity centroid (radius 15) is summed straight
+// from the unblurred level, the 37x37 window of the blurred level that the rotated pattern can reach is
+// staged in LDS, and the 256 binary tests read it there.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlurW = 37, kWinDwords = 10;     // window rows are 40 bytes in LDS
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -637,16 +717,27 @@ constexpr IcTable make_ic_table()
 }
 __device__ __constant__ IcTable c_ic = make_ic_table();
 
-__global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
+// the 256 test pairs as floats (x0, y0, x1, y1)
+struct PatternF { float v[1024]; };
+constexpr PatternF make_pattern_f()
+{
+    constexpr signed char src[1024] = {
+#include "../../include/orbx_pattern.inc"
+    };
+    PatternF t{};
+    for (int i = 0; i < 1024; ++i) t.v[i] = (float)src[i];
+    return t;
+}
+__device__ __constant__ __align__(16) PatternF c_pattern_f = make_pattern_f();
+
+__global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
                                                   const DevLevel* __restrict__ lv, int nlevels,
                                                   const uint32_t* __restrict__ lvlkp, int kp_total,
                                                   const int32_t* __restrict__ lvlcnt,
                                                   orbx_keypoint* __restrict__ okp, uint8_t* __restrict__ odesc,
-                                                  int32_t* __restrict__ ocount, int cap_per_frame, int blur_rounding)
+                                                  int32_t* __restrict__ ocount, int cap_per_frame)
 {
-    __shared__ __align__(16) uint8_t s_patch[4][kPatchW * kPatchStride + 12];
-    __shared__ __align__(16) uint16_t s_h[4][kHCols * kHRows];
-    __shared__ __align__(16) uint8_t s_blur[4][kBlurW * kBlurStride];
+    __shared__ __align__(16) uint32_t s_win[4][kBlurW * kWinDwords + 6];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.y;
@@ -667,73 +758,42 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     const uint32_t key = lvlkp[(unsigned long long)frame * kp_total + L.kp_offset + idx];
     const int kx = (int)(key >> 20) + kMinBorder, ky = (int)((key >> 8) & 0xFFF) + kMinBorder;
     const int resp = (int)(key & 0xFF);
+    const unsigned long long fo = (unsigned long long)frame * pyr_bytes + L.roi;
 
-    uint32_t* patch = reinterpret_cast<uint32_t*>(s_patch[wave]);      // 11 dwords per row
-    uint16_t* hT = s_h[wave];
-    uint8_t* blur = s_blur[wave];
-    const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + L.roi + (long long)(ky - 21) * L.stride + (kx - 21);
-    for (int i = lane; i < kPatchW * 11; i += 64) {
-        const int r = i / 11, d = i - r * 11;
-        patch[i] = load_u32(src + (long long)r * L.stride + 4 * d);
+    // blurred window rows ky-18..ky+18, bytes kx-18..kx+21 (the last three are not used)
+    uint32_t* win = s_win[wave];
+    {
+        const uint8_t* bsrc = blr + fo + (long long)(ky - 18) * L.stride + (kx - 18);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = lane + 64 * k;
+            const int r = i / kWinDwords, d = i - r * kWinDwords;
+            if (i < kBlurW * kWinDwords) win[i] = load_u32(bsrc + (long long)r * L.stride + 4 * d);
+        }
     }
-    wave_sync();
 
     // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc, four pixels per
-    // v_dot4_u32_u8.  m10 = sum u*I = sum (u+15)*I - 15*sum I,  m01 = sum v*I.
+    // v_dot4_u32_u8.  m10 = sum u*I = sum (u+15)*I - 15*sum I,  m01 = sum v*I.  Row v of the disc is read as the
+    // nine dwords starting at column kx-17; bytes outside the disc have weight 0.
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 9; i += 64) {
-        const int rr = i / 9, d = i - rr * 9;          // disc row rr-15, dword d+1 of the patch row
-        const int v = rr - kHalfPatch, av = v < 0 ? -v : v;
-        const uint32_t px = patch[(6 + rr) * 11 + 1 + d];
-        const uint32_t su = __builtin_amdgcn_udot4(px, c_ic.wu[av][d], 0u, false);
-        const uint32_t sm = __builtin_amdgcn_udot4(px, c_ic.wm[av][d], 0u, false);
-        m10 += (int)su - 15 * (int)sm;
-        m01 += v * (int)sm;
+    {
+        const uint8_t* csrc = pyr + fo + (long long)(ky - kHalfPatch) * L.stride + (kx - 17);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = lane + 64 * k;
+            if (i < 31 * 9) {
+                const int rr = i / 9, d = i - rr * 9;
+                const int v = rr - kHalfPatch, av = v < 0 ? -v : v;
+                const uint32_t px = load_u32(csrc + (long long)rr * L.stride + 4 * d);
+                const uint32_t su = __builtin_amdgcn_udot4(px, c_ic.wu[av][d], 0u, false);
+                const uint32_t sm = __builtin_amdgcn_udot4(px, c_ic.wm[av][d], 0u, false);
+                m10 += (int)su - 15 * (int)sm;
+                m01 += v * (int)sm;
+            }
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    // GaussianBlur 7x7 sigma 2 (src/ORBextractor.cc:1085), Q8 taps 18,34,49,55,49,34,18, restricted to the
-    // 37x37 window the rotated pattern can reach.  Horizontal pass: window column j reads patch columns
-    // j..j+6; two v_dot4_u32_u8 per output; results stored transposed ([column][row], 16 bit).
-    constexpr uint32_t T0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), T1 = 49u | (34u << 8) | (18u << 16);
-    for (int i = lane; i < kPatchW * 10; i += 64) {
-        const int g = i / kPatchW, r = i - g * kPatchW;
-        const uint32_t w0 = patch[r * 11 + g], w1 = patch[r * 11 + g + 1], w2 = patch[r * 11 + g + 2];
-        uint16_t* o = hT + (4 * g) * kHRows + r;
-        o[0] = (uint16_t)__builtin_amdgcn_udot4(w1, T1, __builtin_amdgcn_udot4(w0, T0, 0u, false), false);
-        o[kHRows] = (uint16_t)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), T1,
-                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), T0, 0u, false), false);
-        o[2 * kHRows] = (uint16_t)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), T1,
-                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), T0, 0u, false), false);
-        o[3 * kHRows] = (uint16_t)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), T1,
-                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), T0, 0u, false), false);
-    }
-    wave_sync();
-    // Vertical pass: one lane produces window rows 2q and 2q+1 of one column from four aligned dwords
-    // (pairs of vertically adjacent 16-bit sums), four v_dot2_u32_u16 per output.
-    {
-        const uint32_t* hd = reinterpret_cast<const uint32_t*>(hT);
-        constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
-        constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
-        const int simdW = blur_rounding ? (L.w & ~3) : 0;
-        for (int i = lane; i < kBlurW * 19; i += 64) {
-            const int q = i / kBlurW, c = i - q * kBlurW;
-            const uint32_t* col = hd + c * (kHRows / 2) + q;
-            const us16x2 d0 = __builtin_bit_cast(us16x2, col[0]), d1 = __builtin_bit_cast(us16x2, col[1]);
-            const us16x2 d2 = __builtin_bit_cast(us16x2, col[2]), d3 = __builtin_bit_cast(us16x2, col[3]);
-#define ORBX_DOT2(a, w, acc) __builtin_amdgcn_udot2(a, __builtin_bit_cast(us16x2, (uint32_t)(w)), acc, false)
-            const uint32_t se = ORBX_DOT2(d3, E3, ORBX_DOT2(d2, E2, ORBX_DOT2(d1, E1, ORBX_DOT2(d0, E0, 0u))));
-            const uint32_t so = ORBX_DOT2(d3, O3, ORBX_DOT2(d2, O2, ORBX_DOT2(d1, O1, ORBX_DOT2(d0, O0, 0u))));
-#undef ORBX_DOT2
-            const bool even_ties = (kx - 18 + c) < simdW;
-            const uint32_t ve = even_ties ? ((se + 32767u + ((se >> 16) & 1u)) >> 16) : ((se + 32768u) >> 16);
-            const uint32_t vo = even_ties ? ((so + 32767u + ((so >> 16) & 1u)) >> 16) : ((so + 32768u) >> 16);
-            blur[(2 * q) * kBlurStride + c] = (uint8_t)min(ve, 255u);
-            if (2 * q + 1 < kBlurW) blur[(2 * q + 1) * kBlurStride + c] = (uint8_t)min(vo, 255u);
-        }
-    }
-    wave_sync();
 
     // computeOrbDescriptor (src/ORBextractor.cc:107-146)
     constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.0); // (float)(CV_PI/180.f)
@@ -743,17 +803,21 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     const float a = (float)cd, b = (float)sd;
     const size_t orow = (size_t)frame * cap_per_frame + outOff + idx;
     unsigned long long* dout = reinterpret_cast<unsigned long long*>(odesc + orow * 32);
+    wave_sync();
+    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+    // cvRound by adding 1.5 * 2^23: the low bits of the sum's encoding are the rounded integer (ties to even)
+    constexpr float kMagic = 12582912.f;
+    constexpr uint32_t kBias = 0x4B400000u;
+    const float4* pf = reinterpret_cast<const float4*>(c_pattern_f.v);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int t = g * 64 + lane;
-        const float x0 = (float)c_pattern[4 * t], y0 = (float)c_pattern[4 * t + 1];
-        const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
-        const int r0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = blur[(18 + r0) * kBlurStride + 18 + c0];
-        const int t1 = blur[(18 + r1) * kBlurStride + 18 + c1];
+        const float4 pt = pf[g * 64 + lane];
+        const uint32_t r0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)), kMagic)) - kBias;
+        const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)), kMagic)) - kBias;
+        const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)), kMagic)) - kBias;
+        const uint32_t c1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)), kMagic)) - kBias;
+        const int t0 = wb[(int)(18 + r0) * (4 * kWinDwords) + (int)(18 + c0)];
+        const int t1 = wb[(int)(18 + r1) * (4 * kWinDwords) + (int)(18 + c1)];
         const unsigned long long bits = __ballot(t0 < t1);
         if (lane == 0) dout[g] = bits;
     }
@@ -788,6 +852,8 @@ struct orbx_extractor {
     ResizeY* d_ry = nullptr;
     ResizeGroup* d_rg = nullptr;
     uint8_t* d_pyr = nullptr;
+    uint8_t* d_blur = nullptr;   // Gaussian-blurred copy of every level (ROI pixels only), same layout as d_pyr
+    int max_blur_threads = 0;
     uint32_t* d_cand = nullptr;
     uint16_t* d_cellcnt = nullptr;
     uint32_t* d_keys = nullptr;
@@ -849,8 +915,9 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         d.fast_resize = g.fast_resize;
         d.rg_offset = g.rg_offset;
         d.cpr = g.cpr; d.cpr_magic = g.cpr_magic;
-        d.border_threads = 2 * kEdge * (g.stride / 4) + g.h * (8 + g.stride / 4 - (kRoiX + g.w) / 4);
-        ex->max_border_threads = std::max(ex->max_border_threads, d.border_threads);
+        d.border_threads = border_threads(g.w, g.h, g.stride, kEdge, 8, 1 << 20);
+        ex->max_border_threads = std::max(ex->max_border_threads, border_threads(g.w, g.h, g.stride, 3, 1, 2));
+        ex->max_blur_threads = std::max(ex->max_blur_threads, ((g.w + 3) / 4) * ((g.h + kBlurRows - 1) / kBlurRows));
         key_off += (g.cand_cap + 3) & ~3;
         ncmax = std::max(ncmax, g.kp_cap);
         ex->hlv[l] = d;
@@ -883,6 +950,8 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     if (!geo.rg.empty()) HIP_CHECK(hipMemcpy(ex->d_rg, geo.rg.data(), sizeof(ResizeGroup) * geo.rg.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&ex->d_pyr, geo.pyr_bytes * B + 256));
     HIP_CHECK(hipMemset(ex->d_pyr, 0, geo.pyr_bytes * B + 256));
+    HIP_CHECK(hipMalloc(&ex->d_blur, geo.pyr_bytes * B + 256));
+    HIP_CHECK(hipMemset(ex->d_blur, 0, geo.pyr_bytes * B + 256));
     HIP_CHECK(hipMalloc(&ex->d_cand, sizeof(uint32_t) * (size_t)geo.cand_total * B));
     HIP_CHECK(hipMalloc(&ex->d_cellcnt, sizeof(uint16_t) * geo.cells.size() * B));
     HIP_CHECK(hipMalloc(&ex->d_keys, sizeof(uint32_t) * (size_t)ex->key_total * B));
@@ -899,7 +968,7 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_rx, ex->d_ry, ex->d_rg, ex->d_pyr, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
+    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_rx, ex->d_ry, ex->d_rg, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
                     ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : ex->ev) if (e) (void)hipEventDestroy(e);
@@ -938,7 +1007,7 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
             }
         }
         dim3 gb((ex->max_border_threads + 255) / 256, G.nlevels, B);
-        hipLaunchKernelGGL(k_borders, gb, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv);
+        hipLaunchKernelGGL(k_borders, gb, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, 3, 1, 2);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
     {
@@ -964,10 +1033,14 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
     {
+        dim3 gblur((ex->max_blur_threads + 255) / 256, G.nlevels, B);
+        if (ex->params.blur_rounding)
+            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv);
+        else
+            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv);
         dim3 grid((G.kp_total + 3) / 4, B);
-        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels,
-                           ex->d_lvlkp, G.kp_total, ex->d_lvlcnt, d_kps, d_desc, d_counts, cap_per_frame,
-                           ex->params.blur_rounding);
+        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels,
+                           ex->d_lvlkp, G.kp_total, ex->d_lvlcnt, d_kps, d_desc, d_counts, cap_per_frame);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
     HIP_CHECK(hipGetLastError());
@@ -1050,8 +1123,23 @@ int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, p
     if (dst_stride < L.w + 2 * kEdge) return ORBX_ERR_BAD_ARG;
     HIP_CHECK(hipSetDevice(ex->device));
     HIP_CHECK(hipStreamSynchronize(ex->stream));
+    // the batch path fills only the 3 innermost frame pixels: complete this level's frame first
+    hipLaunchKernelGGL(k_borders, dim3((ex->hlv[level].border_threads + 255) / 256), dim3(256), 0, ex->stream,
+                       ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes, 0ull, ex->d_lv + level, kEdge, 8, 1 << 20);
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
     const uint8_t* src = ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes + L.offset + (kRoiX - kEdge);
     HIP_CHECK(hipMemcpy2D(dst, dst_stride, src, L.stride, L.w + 2 * kEdge, L.rows, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride)
+{
+    if (!ex || !dst || frame < 0 || frame >= ex->max_batch || level < 0 || level >= ex->geo.nlevels) return ORBX_ERR_BAD_ARG;
+    const LevelGeom& L = ex->geo.lv[level];
+    if (dst_stride < L.w) return ORBX_ERR_BAD_ARG;
+    HIP_CHECK(hipSetDevice(ex->device));
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(hipMemcpy2D(dst, dst_stride, ex->d_blur + (size_t)frame * ex->geo.pyr_bytes + L.roi, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 
