@@ -44,7 +44,9 @@ struct DevLevel {
     float scale, kp_size;
     int key_offset;   // offset of this level's compact key array inside one frame's key scratch
     int fast_resize;  // every aligned group of 4 destination columns reads <= 8 consecutive source bytes
-    int rg_offset;    // first ResizeGroup record of this level
+    int rg_offset;    // first group record of this level
+    int gpr;          // groups per row of the resize kernel
+    unsigned gpr_magic;
     int cpr;          // 16-byte chunks per ROI row, ceil(w/16)
     unsigned cpr_magic; // ceil(2^32 / cpr): row of flat chunk index i is umulhi(i, cpr_magic)
     int border_threads; // threads of k_borders for this level
@@ -83,12 +85,30 @@ __device__ __forceinline__ int reflect101(int p, int len)
 // divergent border code.
 // ---------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(1))) u128_unaligned { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) u64_unaligned { uint32_t x, y; };
 
 // flat chunk index -> (row, chunk in row) with a precomputed reciprocal (exact for the index range used)
 __device__ __forceinline__ void split_index(uint32_t i, uint32_t cpr, uint32_t magic, uint32_t& row, uint32_t& col)
 {
     row = __umulhi(i, magic);
     col = i - row * cpr;
+}
+
+// Store chunk ch of ROI row y and the parts of the REFLECT_101 frame that mirror it: the dword left of the ROI
+// (columns -4..-1 repeat columns 4..1) with chunk 0, and frame row -j / h-1+j with ROI row j / h-1-j
+// (j = 1..kFrameFill).  Frame columns right of the ROI are ordinary columns of the last chunk(s).
+__device__ __forceinline__ void store_chunk_with_frame(uint8_t* roi, int stride, int h, uint32_t y, uint32_t ch, const uint4 v)
+{
+    uint8_t* row = roi + (unsigned long long)y * stride;
+    const uint32_t left = __builtin_amdgcn_perm(v.y, v.x, 0x01020304u);
+    *reinterpret_cast<uint4*>(row + 16 * ch) = v;
+    if (ch == 0) *reinterpret_cast<uint32_t*>(row - 4) = left;
+    const bool top = y - 1u < (uint32_t)kFrameFill, bottom = (uint32_t)(h - 2) - y < (uint32_t)kFrameFill;
+    if (top || bottom) {
+        uint8_t* mrow = roi + (long long)(top ? -(int)y : 2 * (h - 1) - (int)y) * stride;
+        *reinterpret_cast<uint4*>(mrow + 16 * ch) = v;
+        if (ch == 0) *reinterpret_cast<uint32_t*>(mrow - 4) = left;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img, long long row_stride, long long frame_stride,
@@ -103,52 +123,68 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img,
     if ((int)(16 * ch + 16) <= L.w) {
         const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(s);
         v = make_uint4(t.x, t.y, t.z, t.w);
-    } else {                                   // last chunk of a row: do not read past the source row
+    } else {                                   // last chunks of a row: the ROI's end and the frame columns right of it
         uint32_t t[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) if ((int)(16 * ch) + k < L.w) t[k >> 2] |= (uint32_t)s[k] << (8 * (k & 3));
+        for (int k = 0; k < 16; ++k) {
+            const int x = (int)(16 * ch) + k;
+            if (x < L.w + kFrameFill) t[k >> 2] |= (uint32_t)s[reflect101(x, L.w) - (int)(16 * ch)] << (8 * (k & 3));
+        }
         v = make_uint4(t[0], t[1], t[2], t[3]);
     }
-    *reinterpret_cast<uint4*>(pyr + (unsigned long long)blockIdx.y * pyr_bytes + L.roi + (unsigned long long)y * L.stride + 16 * ch) = v;
+    store_chunk_with_frame(pyr + (unsigned long long)blockIdx.y * pyr_bytes + L.roi, L.stride, L.h, y, ch, v);
 }
 
 // Level l from level l-1: cv::resize INTER_LINEAR for 8-bit (Q11 weights, two-stage rounding).
-// Four adjacent destination columns read at most 8 consecutive source bytes per row; one v_perm_b32
-// pulls a column's two neighbours out of that window as 16-bit lanes, one v_dot2_u32_u16 applies the weights.
+// A thread owns one group of four adjacent destination columns over four consecutive rows, and consecutive
+// lanes own consecutive groups, so each load or store of a wavefront touches a few cache lines.  The four
+// columns read at most 8 consecutive source bytes per row; one v_perm_b32 pulls a column's two neighbours out
+// of that window as 16-bit lanes, one v_dot2_u32_u16 applies the weights.  Frame columns are ordinary groups
+// (their table entries repeat the mirror column); frame rows are second stores of the rows they mirror.
+constexpr int kResizeRows = 4;
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel S, DevLevel D,
-                                                const ResizeY* __restrict__ ryt, const ResizeGroup* __restrict__ rgt)
+                                                const ResizeY* __restrict__ ryt, const ResizeGroupA* __restrict__ rga,
+                                                const ResizeGroupB* __restrict__ rgb)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= (uint32_t)(D.cpr * D.h)) return;
-    uint32_t y, ch;
-    split_index(i, D.cpr, D.cpr_magic, y, ch);
+    if (i >= (uint32_t)(D.gpr * ((D.h + kResizeRows - 1) / kResizeRows))) return;
+    uint32_t rb, gx;
+    split_index(i, D.gpr, D.gpr_magic, rb, gx);
     uint8_t* base = pyr + (unsigned long long)blockIdx.y * pyr_bytes;
-    const ResizeY ey = ryt[D.ry_offset + y];
-    const uint8_t* s0 = base + S.roi + (long long)ey.sy0 * S.stride;
-    const uint8_t* s1 = base + S.roi + (long long)ey.sy1 * S.stride;
-    const uint32_t b0 = (uint32_t)(int)ey.b0, b1 = (uint32_t)(int)ey.b1;
-    const uint4* tp = reinterpret_cast<const uint4*>(rgt + (size_t)(D.rg_offset + 4 * ch));
-    uint32_t out[4];
+    const uint4 ta = *reinterpret_cast<const uint4*>(rga + D.rg_offset + gx);   // sx_first, 4 byte offsets, w0, w1
+    const uint2 tb = *reinterpret_cast<const uint2*>(rgb + D.rg_offset + gx);   // w2, w3
+    const uint32_t wt[4] = {ta.z, ta.w, tb.x, tb.y};
+    uint32_t sel[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint4 ta = tp[2 * g], tb = tp[2 * g + 1];     // {sx_first, 4 byte offsets, w0, w1} {w2, w3, -, -}
-        const int sx0 = (int)ta.x;
-        const uint32_t wt[4] = {ta.z, ta.w, tb.x, tb.y};
-        const uint32_t lo0 = load_u32(s0 + sx0), hi0 = load_u32(s0 + sx0 + 4);
-        const uint32_t lo1 = load_u32(s1 + sx0), hi1 = load_u32(s1 + sx0 + 4);
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t off = (ta.y >> (8 * k)) & 0xFFu;
+        sel[k] = (off | (off << 16)) + 0x0c010c00u;                             // bytes off, off+1 -> 16-bit lanes 0, 1
+    }
+    // all products below fit 24-bit operands: rows < 2^15, strides < 2^13, weights <= 2048, sums >> 4 < 2^15
+    const uint8_t* scol = base + S.roi + (int)ta.x;
+    uint8_t* dcol = base + D.roi + 4 * ((int)gx - 1);
+#pragma unroll
+    for (int r = 0; r < kResizeRows; ++r) {
+        const int y = (int)rb * kResizeRows + r;
+        if (y >= D.h) break;
+        const ResizeY ey = ryt[D.ry_offset + y];
+        const u64_unaligned r0 = *reinterpret_cast<const u64_unaligned*>(scol + __umul24((uint32_t)ey.sy0, (uint32_t)S.stride));
+        const u64_unaligned r1 = *reinterpret_cast<const u64_unaligned*>(scol + __umul24((uint32_t)ey.sy1, (uint32_t)S.stride));
+        const uint32_t b0 = (uint32_t)(int)ey.b0, b1 = (uint32_t)(int)ey.b1;
         uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t sel = ((ta.y >> (8 * k)) & 0xFFu) * 0x00010001u + 0x0c010c00u;   // bytes off, off+1 -> lanes 0, 1
             const us16x2 w = __builtin_bit_cast(us16x2, wt[k]);
-            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(hi0, lo0, sel)), w, 0u, false);
-            const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(hi1, lo1, sel)), w, 0u, false);
-            const uint32_t b = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2u) >> 2) & 0xFFu;
+            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r0.y, r0.x, sel[k])), w, 0u, false);
+            const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r1.y, r1.x, sel[k])), w, 0u, false);
+            const uint32_t b = (((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2) & 0xFFu;
             v |= b << (8 * k);
         }
-        out[g] = v;
+        *reinterpret_cast<uint32_t*>(dcol + __umul24((uint32_t)y, (uint32_t)D.stride)) = v;
+        // frame row -j repeats row j, row h-1+j repeats row h-1-j (j = 1..kFrameFill)
+        const bool top = (uint32_t)(y - 1) < (uint32_t)kFrameFill, bottom = (uint32_t)(D.h - 2 - y) < (uint32_t)kFrameFill;
+        if (top || bottom) *reinterpret_cast<uint32_t*>(dcol + (long long)__mul24(top ? -y : 2 * (D.h - 1) - y, D.stride)) = v;
     }
-    *reinterpret_cast<uint4*>(base + D.roi + (unsigned long long)y * D.stride + 16 * ch) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 // Generic form (per-pixel table, exact 2x decimation rerouted to the 2x2 mean as OpenCV does): used for
@@ -320,12 +356,17 @@ __device__ __forceinline__ uint32_t fast_pretest(const uint32_t (&m3)[3], const 
     return as_u32(pmax(dark, zero - bright));
 }
 
+// number of set bits of m below the calling lane
+__device__ __forceinline__ int lanes_below(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // One wavefront per cell, four cells per workgroup; no workgroup barrier anywhere.
 //   tile load -> [pass 1: packed pretest of 256 pixels per round, survivors queued -> pass 2: exact score of the
 //   queued survivors whenever the queue fills, and at the end] -> pass 3: lane r owns row r of the cell: strict
 //   local maxima among the scored pixels, threshold choice, raster-ordered emission.
 // TS/TR: tile row stride (bytes) and rows, SS/SR: score tile stride and rows.
-constexpr int kFastQueue = 448;     // a flush leaves < 192 entries, one round adds <= 256
 
 template <int TS, int TR, int SS, int SR>
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
@@ -335,10 +376,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 {
     __shared__ __align__(16) uint8_t s_tile[4][TR * TS];
     __shared__ __align__(16) uint8_t s_score[4][SR * SS];
-    __shared__ unsigned long long s_scored[4][64];
-    __shared__ uint16_t s_queue[4][kFastQueue];
+    __shared__ unsigned long long s_mask[4][2][64];
+    // one list per cell: the scored pixels (corners at the lower threshold) found so far, then the pretest survivors
+    // waiting for their score; together never more than the pixels of the cell
+    constexpr int QCAP = ((TR - 6) * (TR - 6) + 7) & ~7;
+    __shared__ uint16_t s_queue[4][QCAP];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything derived from it stays scalar
     const int cell = blockIdx.x * 4 + wave;
     if (cell >= ncells) return;
     const CellRec c = cells[cell];
@@ -346,22 +391,23 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const uint8_t* src = pyr + (unsigned long long)blockIdx.y * pyr_bytes + L.roi + (long long)c.y0 * L.stride + c.x0;
     uint8_t* tile = s_tile[wave];
     uint8_t* score = s_score[wave];
-    unsigned long long* scored = s_scored[wave];
+    unsigned long long* mskIni = s_mask[wave][0];
+    unsigned long long* mskMin = s_mask[wave][1];
     uint16_t* queue = s_queue[wave];
     const int cw = c.cw, ch = c.ch;
     const int tw = cw + 6, th = ch + 6;
-    const int dpr = (tw + 3) >> 2; // dwords per tile row (<= 17)
     {
-        const int d = lane & 15;
-        uint32_t* trow = reinterpret_cast<uint32_t*>(tile);
-        for (int r = lane >> 4; r < th; r += 4) {
-            const uint8_t* p = src + (long long)r * L.stride + 4 * d;
-            if (d < dpr) trow[r * (TS / 4) + d] = load_u32(p);
-            if (d + 16 < dpr) trow[r * (TS / 4) + d + 16] = load_u32(p + 64);
-        }
+        // 16 bytes per lane, TS/16 lanes per tile row
+        constexpr int LPR = TS / 16, RPI = 64 / LPR;
+        const int r0 = lane / LPR, j = lane - r0 * LPR;
+        if (lane < LPR * RPI && 16 * j < tw)
+            for (int r = r0; r < th; r += RPI) {
+                const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(src + ((uint32_t)r * (uint32_t)L.stride + 16u * (uint32_t)j));
+                *reinterpret_cast<uint4*>(tile + r * TS + 16 * j) = make_uint4(t.x, t.y, t.z, t.w);
+            }
     }
-    for (int i = lane; i < (ch + 2) * (SS / 4); i += 64) reinterpret_cast<uint32_t*>(score)[i] = 0;
-    scored[lane] = 0;
+    for (int i = lane; i < (ch + 2) * (SS / 16); i += 64) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
+    mskIni[lane] = 0; mskMin[lane] = 0;
     wave_sync();
 
     const int lowTh = min(iniTh, minTh);
@@ -371,7 +417,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const int rows_per_round = 64 >> gsh;
     const int x = 4 * g;
     const uint32_t colmask = g < gpr ? (1u << min(cw - x, 4)) - 1u : 0u;   // pixels past the cell's last column
-    int nq = 0;                                     // wave-uniform queue fill
+    int nq = 0, nsq = 0;                            // wave-uniform queue fills
     for (int y0 = 0; y0 < ch; y0 += rows_per_round) {
         const int y = y0 + (lane >> gsh);
         uint32_t pm = 0;
@@ -395,44 +441,49 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         for (int j = 0; j < 4; ++j) {
             const bool on = (pm >> j) & 1u;
             const unsigned long long m = __ballot(on);
-            if (on) queue[nq + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(idx + j);
+            if (on) queue[nsq + nq + lanes_below(m)] = (uint16_t)(idx + j);
             nq += __popcll(m);
         }
         if (nq >= 192 || y0 + rows_per_round >= ch) {
-            // pass 2: exact score of the queued survivors
+            // pass 2: exact score of the queued survivors; corners go to the score tile and the scored list
+            // (a scored entry is written at or below the slot its lane just read, so no waiting entry is overwritten)
             wave_sync();
-            for (int e = lane; e < nq; e += 64) {
-                const int i = queue[e];
-                const int yy = i >> 6, xx = i & 63;
-                const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
-                if (sc >= lowTh && sc >= 1) {
-                    score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
-                    atomicOr(&scored[yy], 1ull << xx);
+            const int first = nsq;
+            for (int e0 = 0; e0 < nq; e0 += 64) {
+                const int e = e0 + lane;
+                bool keep = false;
+                int i = 0;
+                if (e < nq) {
+                    i = queue[first + e];
+                    const int yy = i >> 6, xx = i & 63;
+                    const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
+                    keep = sc >= lowTh && sc >= 1;
+                    if (keep) score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
                 }
+                const unsigned long long m = __ballot(keep);
+                if (keep) queue[nsq + lanes_below(m)] = (uint16_t)i;
+                nsq += __popcll(m);
             }
             wave_sync();
             nq = 0;
         }
     }
-    // pass 3: lane r owns row r: strict local maxima inside the cell among the scored pixels
+    // pass 3: strict local maxima inside the cell among the scored pixels, one lane per scored pixel; row masks
+    // of the maxima at the two thresholds
     const int tIni = max(iniTh, 1), tMin = max(minTh, 1);
-    unsigned long long mi = 0, mm = 0;
-    if (lane < ch) {
-        unsigned long long todo = scored[lane];
-        while (todo) {
-            const int xx = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const uint8_t* sp = &score[(lane + 1) * SS + xx + 1];
-            const int sc = sp[0];
-            const bool mx = sc > sp[-1] && sc > sp[1] &&
-                            sc > sp[-SS - 1] && sc > sp[-SS] && sc > sp[-SS + 1] &&
-                            sc > sp[SS - 1] && sc > sp[SS] && sc > sp[SS + 1];
-            if (mx) {
-                if (sc >= tMin) mm |= 1ull << xx;
-                if (sc >= tIni) mi |= 1ull << xx;
-            }
-        }
+    for (int e = lane; e < nsq; e += 64) {
+        const int i = queue[e];
+        const int yy = i >> 6, xx = i & 63;
+        const uint8_t* sp = &score[(yy + 1) * SS + xx + 1];
+        const int sc = sp[0];
+        const bool mx = sc > sp[-1] && sc > sp[1] &&
+                        sc > sp[-SS - 1] && sc > sp[-SS] && sc > sp[-SS + 1] &&
+                        sc > sp[SS - 1] && sc > sp[SS] && sc > sp[SS + 1];
+        if (mx && sc >= tMin) atomicOr(&mskMin[yy], 1ull << xx);
+        if (mx && sc >= tIni) atomicOr(&mskIni[yy], 1ull << xx);
     }
+    wave_sync();
+    const unsigned long long mi = mskIni[lane], mm = mskMin[lane];   // lane r owns row r (rows >= ch are empty)
     // threshold choice (FAST at iniThFAST, and only if that finds nothing, at minThFAST) and emission
     unsigned long long mask = __any(mi != 0ull) ? mi : mm;
     const int cnt = __popcll(mask);
@@ -587,9 +638,13 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     if (i >= gpr * strips) return;
     const int strip = i / gpr, g = i - strip * gpr;
     const int y0 = strip * kBlurRows, x = 4 * g;
+    // wavefront-uniform bases (three rows up and four bytes left of the ROI origin for the source) plus a
+    // 32-bit lane offset
     const unsigned long long fo = (unsigned long long)blockIdx.z * pyr_bytes + L.roi;
-    const uint8_t* src = pyr + fo + (long long)(y0 - 3) * L.stride + (x - 4);
-    uint8_t* dst = blr + fo + (long long)y0 * L.stride + x;
+    const uint32_t stride = (uint32_t)L.stride;
+    const uint8_t* src = pyr + fo - 3 * stride - 4;
+    uint8_t* dst = blr + fo;
+    const uint32_t vo = __umul24((uint32_t)y0, stride) + (uint32_t)x;
     const bool even_ties = MODE != 0 && x < (L.w & ~3);
     constexpr uint32_t T0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), T1 = 49u | (34u << 8) | (18u << 16);
     constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
@@ -600,7 +655,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
         uint32_t h[2][4];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const u96 t = *reinterpret_cast<const u96*>(src + (long long)(2 * j + r) * L.stride);
+            const u96 t = *reinterpret_cast<const u96*>(src + (vo + (uint32_t)(2 * j + r) * stride));
             h[r][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 1), T1,
                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 1), T0, 0u, false), false);
             h[r][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 2), T1,
@@ -630,8 +685,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
             const uint32_t e23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[3], te[2], 0x07060302u)), lim));
             const uint32_t o01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[1], to[0], 0x07060302u)), lim));
             const uint32_t o23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[3], to[2], 0x07060302u)), lim));
-            if (y0 + 2 * m < L.h) *reinterpret_cast<uint32_t*>(dst + (long long)(2 * m) * L.stride) = __builtin_amdgcn_perm(e23, e01, 0x06040200u);
-            if (y0 + 2 * m + 1 < L.h) *reinterpret_cast<uint32_t*>(dst + (long long)(2 * m + 1) * L.stride) = __builtin_amdgcn_perm(o23, o01, 0x06040200u);
+            if (y0 + 2 * m < L.h) *reinterpret_cast<uint32_t*>(dst + (vo + (uint32_t)(2 * m) * stride)) = __builtin_amdgcn_perm(e23, e01, 0x06040200u);
+            if (y0 + 2 * m + 1 < L.h) *reinterpret_cast<uint32_t*>(dst + (vo + (uint32_t)(2 * m + 1) * stride)) = __builtin_amdgcn_perm(o23, o01, 0x06040200u);
         }
     }
 }
@@ -850,10 +905,12 @@ struct orbx_extractor {
     CellRec* d_cells = nullptr;
     ResizeX* d_rx = nullptr;
     ResizeY* d_ry = nullptr;
-    ResizeGroup* d_rg = nullptr;
+    ResizeGroupA* d_rga = nullptr;
+    ResizeGroupB* d_rgb = nullptr;
     uint8_t* d_pyr = nullptr;
     uint8_t* d_blur = nullptr;   // Gaussian-blurred copy of every level (ROI pixels only), same layout as d_pyr
     int max_blur_threads = 0;
+    int generic_levels = 0;  // levels produced by k_resize_generic
     uint32_t* d_cand = nullptr;
     uint16_t* d_cellcnt = nullptr;
     uint32_t* d_keys = nullptr;
@@ -913,10 +970,11 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         d.area2x = g.area2x; d.rx_offset = g.rx_offset; d.ry_offset = g.ry_offset; d.scale = g.scale; d.kp_size = g.kp_size;
         d.key_offset = key_off;
         d.fast_resize = g.fast_resize;
-        d.rg_offset = g.rg_offset;
+        if (l > 0 && !g.fast_resize) ++ex->generic_levels;
+        d.rg_offset = g.rg_offset; d.gpr = g.gpr; d.gpr_magic = g.gpr_magic;
         d.cpr = g.cpr; d.cpr_magic = g.cpr_magic;
         d.border_threads = border_threads(g.w, g.h, g.stride, kEdge, 8, 1 << 20);
-        ex->max_border_threads = std::max(ex->max_border_threads, border_threads(g.w, g.h, g.stride, 3, 1, 2));
+        ex->max_border_threads = std::max(ex->max_border_threads, border_threads(g.w, g.h, g.stride, kFrameFill, 1, 2));
         ex->max_blur_threads = std::max(ex->max_blur_threads, ((g.w + 3) / 4) * ((g.h + kBlurRows - 1) / kBlurRows));
         key_off += (g.cand_cap + 3) & ~3;
         ncmax = std::max(ncmax, g.kp_cap);
@@ -946,8 +1004,10 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK(hipMemcpy(ex->d_cells, geo.cells.data(), sizeof(CellRec) * geo.cells.size(), hipMemcpyHostToDevice));
     if (!geo.rx.empty()) HIP_CHECK(hipMemcpy(ex->d_rx, geo.rx.data(), sizeof(ResizeX) * geo.rx.size(), hipMemcpyHostToDevice));
     if (!geo.ry.empty()) HIP_CHECK(hipMemcpy(ex->d_ry, geo.ry.data(), sizeof(ResizeY) * geo.ry.size(), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMalloc(&ex->d_rg, sizeof(ResizeGroup) * std::max<size_t>(geo.rg.size(), 1)));
-    if (!geo.rg.empty()) HIP_CHECK(hipMemcpy(ex->d_rg, geo.rg.data(), sizeof(ResizeGroup) * geo.rg.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&ex->d_rga, sizeof(ResizeGroupA) * std::max<size_t>(geo.rga.size(), 1)));
+    HIP_CHECK(hipMalloc(&ex->d_rgb, sizeof(ResizeGroupB) * std::max<size_t>(geo.rgb.size(), 1)));
+    if (!geo.rga.empty()) HIP_CHECK(hipMemcpy(ex->d_rga, geo.rga.data(), sizeof(ResizeGroupA) * geo.rga.size(), hipMemcpyHostToDevice));
+    if (!geo.rgb.empty()) HIP_CHECK(hipMemcpy(ex->d_rgb, geo.rgb.data(), sizeof(ResizeGroupB) * geo.rgb.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&ex->d_pyr, geo.pyr_bytes * B + 256));
     HIP_CHECK(hipMemset(ex->d_pyr, 0, geo.pyr_bytes * B + 256));
     HIP_CHECK(hipMalloc(&ex->d_blur, geo.pyr_bytes * B + 256));
@@ -968,7 +1028,7 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_rx, ex->d_ry, ex->d_rg, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
+    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_rx, ex->d_ry, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
                     ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : ex->ev) if (e) (void)hipEventDestroy(e);
@@ -997,17 +1057,19 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
         for (int l = 1; l < G.nlevels; ++l) {
             const DevLevel& D = ex->hlv[l];
             if (D.fast_resize) {
-                dim3 g2((D.cpr * D.h + 255) / 256, B);
+                dim3 g2((D.gpr * ((D.h + kResizeRows - 1) / kResizeRows) + 255) / 256, B);
                 hipLaunchKernelGGL(k_resize, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
-                                   ex->d_ry, ex->d_rg);
+                                   ex->d_ry, ex->d_rga, ex->d_rgb);
             } else {
                 dim3 g2((D.w + 255) / 256, (D.h + 3) / 4, B);
                 hipLaunchKernelGGL(k_resize_generic, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
                                    ex->d_rx, ex->d_ry);
             }
         }
-        dim3 gb((ex->max_border_threads + 255) / 256, G.nlevels, B);
-        hipLaunchKernelGGL(k_borders, gb, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, 3, 1, 2);
+        if (ex->generic_levels) {               // the generic resize writes no frame pixels
+            dim3 gb((ex->max_border_threads + 255) / 256, G.nlevels, B);
+            hipLaunchKernelGGL(k_borders, gb, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, kFrameFill, 1, 2);
+        }
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
     {
@@ -1018,7 +1080,7 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
                                (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total, ex->d_cellcnt, nc,
                                ex->params.ini_th_fast, ex->params.min_th_fast);
         else
-            hipLaunchKernelGGL((k_fast_cells<72, kMaxCellDim + 8, 64, kMaxCellDim + 2>), grid, dim3(256), 0, st, ex->d_pyr,
+            hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2>), grid, dim3(256), 0, st, ex->d_pyr,
                                (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total, ex->d_cellcnt, nc,
                                ex->params.ini_th_fast, ex->params.min_th_fast);
     }

@@ -106,7 +106,7 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
     if (rc) return rc;
     g.width = width; g.height = height; g.nlevels = p.nlevels;
     g.lv.assign(p.nlevels, LevelGeom());
-    g.cells.clear(); g.rx.clear(); g.ry.clear(); g.rg.clear();
+    g.cells.clear(); g.rx.clear(); g.ry.clear(); g.rga.clear(); g.rgb.clear();
     size_t off = 0;
     int cand_off = 0, kp_off = 0;
     g.out_cap = 0; g.max_cell_dim = 0;
@@ -120,11 +120,16 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
         L.kp_size = (float)(int)(kPatch * g.tables.scale[l]);
         L.quota = g.tables.quota[l];
         L.rows = L.h + 2 * kEdge;
-        L.cpr = (L.w + 15) / 16;
+        L.cpr = (L.w + kFrameFill + 15) / 16;   // chunks also cover the frame columns the producers fill
         L.cpr_magic = (unsigned)((0x100000000ull + L.cpr - 1) / L.cpr);
         for (uint32_t i = 0, n = (uint32_t)L.cpr * (uint32_t)L.h; i < n; ++i)     // the reciprocal must be exact over the index range
             if ((uint32_t)(((uint64_t)i * L.cpr_magic) >> 32) != i / (uint32_t)L.cpr) { set_error("internal: chunk reciprocal inexact"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+        L.gpr = 1 + (L.w + kFrameFill + 3) / 4;
+        L.gpr_magic = (unsigned)((0x100000000ull + L.gpr - 1) / L.gpr);
+        for (uint32_t i = 0, n = (uint32_t)L.gpr * (uint32_t)((L.h + 3) / 4); i < n; ++i)
+            if ((uint32_t)(((uint64_t)i * L.gpr_magic) >> 32) != i / (uint32_t)L.gpr) { set_error("internal: group reciprocal inexact"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
         L.stride = (kRoiX + L.w + kEdge + 63) & ~63;
+        if (L.stride % 512 == 0) L.stride += 64;   // rows a multiple of 512 bytes apart fall on the same memory channels
         L.offset = off;
         L.roi = off + (size_t)kEdge * L.stride + kRoiX;
         off += ((size_t)L.stride * L.rows + 255) & ~(size_t)255;
@@ -189,25 +194,37 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
         g.out_cap += L.kp_cap;
 
         L.area2x = 0; L.fast_resize = 0; L.rx_offset = (int)g.rx.size(); L.ry_offset = (int)g.ry.size();
-        L.rg_offset = (int)g.rg.size();
+        L.rg_offset = (int)g.rga.size();
         if (l > 0) {
             build_resize_tables(g.lv[l - 1].w, g.lv[l - 1].h, L.w, L.h, g.rx, g.ry, L.area2x);
             // fast kernel: every aligned group of four destination columns must read <= 8 consecutive source bytes
+            // Group records: group 0 is the frame dword left of the ROI, then the ROI and kFrameFill frame columns
+            // right of it.  Frame columns repeat their REFLECT_101 mirror column (-j -> j, w-1+j -> w-1-j), so the
+            // resize kernel writes the part of the frame that later stages read; columns beyond repeat the last one.
             L.fast_resize = L.area2x ? 0 : 1;
-            for (int x0 = 0; x0 + 3 < L.w && L.fast_resize; x0 += 4)
-                if (g.rx[L.rx_offset + x0 + 3].sx + 1 - g.rx[L.rx_offset + x0].sx > 7) L.fast_resize = 0;
-            // group records cover whole 16-byte chunks; columns past the ROI repeat the last column (their
-            // output lands in the frame area and is overwritten by the border pass)
-            for (int x0 = 0; x0 < 16 * L.cpr && L.fast_resize; x0 += 4) {
-                ResizeGroup r{};
-                r.sx_first = g.rx[L.rx_offset + std::min(x0, L.w - 1)].sx;
+            const size_t mark = g.rga.size();
+            for (int gx = 0; gx < L.gpr && L.fast_resize; ++gx) {
+                ResizeGroupA ra{}; ResizeGroupB rb{};
+                int col[4], lo = 1 << 30, hi = -1;
                 for (int k = 0; k < 4; ++k) {
-                    const ResizeX& e = g.rx[L.rx_offset + std::min(x0 + k, L.w - 1)];
-                    r.offs |= (uint32_t)(e.sx - r.sx_first) << (8 * k);
-                    r.w[k] = (uint32_t)(uint16_t)e.a0 | ((uint32_t)(uint16_t)e.a1 << 16);
+                    int x = std::min(4 * (gx - 1) + k, L.w + kFrameFill - 1);
+                    if (x < 0) x = -x;
+                    if (x >= L.w) x = 2 * L.w - 2 - x;
+                    col[k] = std::min(std::max(x, 0), L.w - 1);
+                    lo = std::min(lo, (int)g.rx[L.rx_offset + col[k]].sx);
+                    hi = std::max(hi, (int)g.rx[L.rx_offset + col[k]].sx);
                 }
-                g.rg.push_back(r);
+                if (hi + 1 - lo > 7) { L.fast_resize = 0; break; }   // both neighbours of every column inside 8 bytes
+                ra.sx_first = lo;
+                for (int k = 0; k < 4; ++k) {
+                    const ResizeX& e = g.rx[L.rx_offset + col[k]];
+                    ra.offs |= (uint32_t)(e.sx - lo) << (8 * k);
+                    const uint32_t wt = (uint32_t)(uint16_t)e.a0 | ((uint32_t)(uint16_t)e.a1 << 16);
+                    if (k < 2) ra.w01[k] = wt; else rb.w23[k - 2] = wt;
+                }
+                g.rga.push_back(ra); g.rgb.push_back(rb);
             }
+            if (!L.fast_resize) { g.rga.resize(mark); g.rgb.resize(mark); }
         }
     }
     g.pyr_bytes = off;

@@ -15,6 +15,7 @@ constexpr int kMinBorder = 16;   // EDGE_THRESHOLD-3, src/ORBextractor.cc:772
 constexpr int kMaxLevels = 32;
 constexpr int kRoiX = 32;        // column of the ROI origin inside a padded row (keeps ROI rows 32-byte aligned)
 constexpr int kMaxRoots = 64;
+constexpr int kFrameFill = 3;    // pixels of the REFLECT_101 frame that later stages read (7x7 Gaussian of ROI pixels)
 
 void set_error(const std::string& s);
 
@@ -38,9 +39,12 @@ struct CellRec {
 };
 
 struct ResizeX { int32_t sx; int16_t a0, a1; };          // source column and Q11 weights of one destination column
-// Four adjacent destination columns: first source column, byte offset of each column's left neighbour
-// from it (one byte each), and the packed Q11 weights a0 | a1 << 16 of each column.  32 bytes.
-struct ResizeGroup { int32_t sx_first; uint32_t offs; uint32_t w[4]; uint32_t pad[2]; };
+// Four adjacent destination columns (a group): first source column, byte offset of each column's left
+// neighbour from it (one byte each), and the packed Q11 weights a0 | a1 << 16 of each column, split into a
+// 16-byte and an 8-byte array so that consecutive lanes read consecutive words.  Group 0 of a level is the
+// frame dword left of the ROI (columns -4..-1), group 1 + x/4 holds ROI column x.
+struct ResizeGroupA { int32_t sx_first; uint32_t offs; uint32_t w01[2]; };
+struct ResizeGroupB { uint32_t w23[2]; };
 struct ResizeY { int16_t sy0, sy1; int16_t b0, b1; };    // clamped source rows and Q11 weights of one destination row
 
 struct LevelGeom {
@@ -57,8 +61,10 @@ struct LevelGeom {
     int area2x;             // resize from the previous level is an exact 2x2 decimation (OpenCV reroutes to INTER_AREA)
     int rx_offset, ry_offset; // offsets into the ResizeX / ResizeY tables (rx_offset is a multiple of 4)
     int fast_resize;        // every aligned group of 4 destination columns reads <= 8 consecutive source bytes
-    int rg_offset;          // first ResizeGroup record of this level (4 per 16-byte chunk, cpr chunks)
-    int cpr;                // 16-byte chunks per ROI row, ceil(w/16)
+    int rg_offset;          // first group record of this level
+    int gpr;                // groups per row that the resize kernel writes: 1 + ceil((w + kFrameFill) / 4)
+    unsigned gpr_magic;     // ceil(2^32 / gpr)
+    int cpr;                // 16-byte chunks per row that the pyramid kernels write, ceil((w + kFrameFill)/16)
     unsigned cpr_magic;     // ceil(2^32 / cpr)
     float scale;            // mvScaleFactor[level]
     float kp_size;          // (float)(int)(31*scale), src/ORBextractor.cc:836,845
@@ -71,7 +77,8 @@ struct Geometry {
     std::vector<CellRec> cells;
     std::vector<ResizeX> rx;
     std::vector<ResizeY> ry;
-    std::vector<ResizeGroup> rg;
+    std::vector<ResizeGroupA> rga;
+    std::vector<ResizeGroupB> rgb;
     size_t pyr_bytes = 0;     // one frame's pyramid block
     int cand_total = 0;       // one frame's candidate slots (u32)
     int kp_total = 0;         // one frame's per-level selected-keypoint slots
