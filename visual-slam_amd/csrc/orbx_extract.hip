@@ -66,6 +66,19 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Frame-major work split for one-dimensional grids of 8 * ceil(B/8) * chunks workgroups.  Workgroups are dealt
+// round-robin over the 8 XCDs (observed behaviour, relied on for locality only), so workgroups whose index is
+// congruent mod 8 share an L2: all chunks of frame f go to indices congruent to f mod 8, one frame after the
+// other, and the lines of a frame that several chunks touch are fetched from memory once.
+__device__ __forceinline__ bool frame_chunk(uint32_t id, uint32_t chunks, int n_frames, int& frame, uint32_t& chunk)
+{
+    const uint32_t j = id >> 3, fh = j / chunks;
+    chunk = j - fh * chunks;
+    frame = (int)(fh * 8u + (id & 7u));
+    return frame < n_frames;
+}
+__host__ inline unsigned frame_chunk_grid(unsigned chunks, int n_frames) { return 8u * (unsigned)((n_frames + 7) / 8) * chunks; }
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     // one reflection is enough for |overshoot| <= 19 < len
@@ -112,13 +125,15 @@ __device__ __forceinline__ void store_chunk_with_frame(uint8_t* roi, int stride,
 }
 
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img, long long row_stride, long long frame_stride,
-                                                uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L)
+                                                uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L, int n_frames)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    int frame; uint32_t blk;
+    if (!frame_chunk(blockIdx.x, (L.cpr * L.h + 255) >> 8, n_frames, frame, blk)) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
     if (i >= (uint32_t)(L.cpr * L.h)) return;
     uint32_t y, ch;
     split_index(i, L.cpr, L.cpr_magic, y, ch);
-    const uint8_t* s = img + (long long)blockIdx.y * frame_stride + (long long)y * row_stride + 16 * ch;
+    const uint8_t* s = img + (long long)frame * frame_stride + (long long)y * row_stride + 16 * ch;
     uint4 v;
     if ((int)(16 * ch + 16) <= L.w) {
         const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(s);
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img,
         }
         v = make_uint4(t[0], t[1], t[2], t[3]);
     }
-    store_chunk_with_frame(pyr + (unsigned long long)blockIdx.y * pyr_bytes + L.roi, L.stride, L.h, y, ch, v);
+    store_chunk_with_frame(pyr + (unsigned long long)frame * pyr_bytes + L.roi, L.stride, L.h, y, ch, v);
 }
 
 // Level l from level l-1: cv::resize INTER_LINEAR for 8-bit (Q11 weights, two-stage rounding).
@@ -144,13 +159,16 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img,
 constexpr int kResizeRows = 4;
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel S, DevLevel D,
                                                 const ResizeY* __restrict__ ryt, const ResizeGroupA* __restrict__ rga,
-                                                const ResizeGroupB* __restrict__ rgb)
+                                                const ResizeGroupB* __restrict__ rgb, int n_frames)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= (uint32_t)(D.gpr * ((D.h + kResizeRows - 1) / kResizeRows))) return;
+    const uint32_t nthreads = (uint32_t)(D.gpr * ((D.h + kResizeRows - 1) / kResizeRows));
+    int frame; uint32_t blk;
+    if (!frame_chunk(blockIdx.x, (nthreads + 255) >> 8, n_frames, frame, blk)) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= nthreads) return;
     uint32_t rb, gx;
     split_index(i, D.gpr, D.gpr_magic, rb, gx);
-    uint8_t* base = pyr + (unsigned long long)blockIdx.y * pyr_bytes;
+    uint8_t* base = pyr + (unsigned long long)frame * pyr_bytes;
     const uint4 ta = *reinterpret_cast<const uint4*>(rga + D.rg_offset + gx);   // sx_first, 4 byte offsets, w0, w1
     const uint2 tb = *reinterpret_cast<const uint2*>(rgb + D.rg_offset + gx);   // w2, w3
     const uint32_t wt[4] = {ta.z, ta.w, tb.x, tb.y};
@@ -372,7 +390,7 @@ template <int TS, int TR, int SS, int SR>
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
                                                     const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
                                                     uint32_t* __restrict__ cand, int cand_total,
-                                                    uint16_t* __restrict__ cellcnt, int ncells, int iniTh, int minTh)
+                                                    uint16_t* __restrict__ cellcnt, int ncells, int iniTh, int minTh, int n_frames)
 {
     __shared__ __align__(16) uint8_t s_tile[4][TR * TS];
     __shared__ __align__(16) uint8_t s_score[4][SR * SS];
@@ -384,11 +402,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything derived from it stays scalar
-    const int cell = blockIdx.x * 4 + wave;
+    int frame; uint32_t blk;
+    if (!frame_chunk(blockIdx.x, (ncells + 3) >> 2, n_frames, frame, blk)) return;
+    const int cell = (int)blk * 4 + wave;
     if (cell >= ncells) return;
     const CellRec c = cells[cell];
     const DevLevel& L = lv[c.level];
-    const uint8_t* src = pyr + (unsigned long long)blockIdx.y * pyr_bytes + L.roi + (long long)c.y0 * L.stride + c.x0;
+    const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + L.roi + (long long)c.y0 * L.stride + c.x0;
     uint8_t* tile = s_tile[wave];
     uint8_t* score = s_score[wave];
     unsigned long long* mskIni = s_mask[wave][0];
@@ -491,7 +511,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
     const int total = __shfl(inc, 63, 64);
     int pos = inc - cnt;
-    uint32_t* out = cand + (unsigned long long)blockIdx.y * cand_total + L.cand_offset + c.slot;
+    uint32_t* out = cand + (unsigned long long)frame * cand_total + L.cand_offset + c.slot;
     while (mask) {
         const int xx = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -499,7 +519,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         if (pos < c.cap) out[pos] = ((uint32_t)(xx + 3 + c.offx) << 20) | ((uint32_t)(lane + 3 + c.offy) << 8) | (uint32_t)sc;
         ++pos;
     }
-    if (lane == 0) cellcnt[(unsigned long long)blockIdx.y * ncells + cell] = (uint16_t)min(total, c.cap);
+    if (lane == 0) cellcnt[(unsigned long long)frame * ncells + cell] = (uint16_t)min(total, c.cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -629,18 +649,21 @@ struct __attribute__((packed, aligned(4))) u96 { uint32_t a, b, c; };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
-                                              const DevLevel* __restrict__ lv)
+                                              const DevLevel* __restrict__ lv, int nlevels, int blocks_per_level, int n_frames)
 {
-    const DevLevel& L = lv[blockIdx.y];
+    int frame; uint32_t chunk;
+    if (!frame_chunk(blockIdx.x, (uint32_t)(nlevels * blocks_per_level), n_frames, frame, chunk)) return;
+    const uint32_t level = chunk / (uint32_t)blocks_per_level, blk = chunk - level * (uint32_t)blocks_per_level;
+    const DevLevel& L = lv[level];
     const int gpr = (L.w + 3) >> 2;
     const int strips = (L.h + kBlurRows - 1) / kBlurRows;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)blk * 256 + threadIdx.x;
     if (i >= gpr * strips) return;
     const int strip = i / gpr, g = i - strip * gpr;
     const int y0 = strip * kBlurRows, x = 4 * g;
     // wavefront-uniform bases (three rows up and four bytes left of the ROI origin for the source) plus a
     // 32-bit lane offset
-    const unsigned long long fo = (unsigned long long)blockIdx.z * pyr_bytes + L.roi;
+    const unsigned long long fo = (unsigned long long)frame * pyr_bytes + L.roi;
     const uint32_t stride = (uint32_t)L.stride;
     const uint8_t* src = pyr + fo - 3 * stride - 4;
     uint8_t* dst = blr + fo;
@@ -785,107 +808,129 @@ constexpr PatternF make_pattern_f()
 }
 __device__ __constant__ __align__(16) PatternF c_pattern_f = make_pattern_f();
 
+// A wavefront describes kKpPerWave consecutive keypoint slots one after the other, so that what depends only on
+// the lane (disc weights, pattern points, load offsets in units of rows and bytes) is set up once.
+constexpr int kKpPerWave = 4;
+
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
                                                   const DevLevel* __restrict__ lv, int nlevels,
                                                   const uint32_t* __restrict__ lvlkp, int kp_total,
                                                   const int32_t* __restrict__ lvlcnt,
                                                   orbx_keypoint* __restrict__ okp, uint8_t* __restrict__ odesc,
-                                                  int32_t* __restrict__ ocount, int cap_per_frame)
+                                                  int32_t* __restrict__ ocount, int cap_per_frame, int n_frames)
 {
     __shared__ __align__(16) uint32_t s_win[4][kBlurW * kWinDwords + 6];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int frame = blockIdx.y;
-    const int slot = blockIdx.x * 4 + wave;
-    // locate (level, index) of this slot and the output offset of the level
-    int level = -1, idx = 0, outOff = 0, total = 0;
-    for (int l = 0; l < nlevels; ++l) {
-        const int cnt = lvlcnt[frame * nlevels + l];
-        const int o = lv[l].kp_offset;
-        if (slot >= o && slot < o + lv[l].kp_cap) { level = l; idx = slot - o; outOff = total; }
-        total += cnt;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) ocount[frame] = total;
-    if (level < 0) return;
-    if (idx >= lvlcnt[frame * nlevels + level]) return;
-    if (outOff + idx >= cap_per_frame) return;
-    const DevLevel& L = lv[level];
-    const uint32_t key = lvlkp[(unsigned long long)frame * kp_total + L.kp_offset + idx];
-    const int kx = (int)(key >> 20) + kMinBorder, ky = (int)((key >> 8) & 0xFFF) + kMinBorder;
-    const int resp = (int)(key & 0xFF);
-    const unsigned long long fo = (unsigned long long)frame * pyr_bytes + L.roi;
-
-    // blurred window rows ky-18..ky+18, bytes kx-18..kx+21 (the last three are not used)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // slot arithmetic stays scalar
+    int frame; uint32_t chunk;
+    if (!frame_chunk(blockIdx.x, (kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), n_frames, frame, chunk)) return;
+    const int slot0 = ((int)chunk * 4 + wave) * kKpPerWave;
+    if (slot0 >= kp_total) return;
     uint32_t* win = s_win[wave];
-    {
-        const uint8_t* bsrc = blr + fo + (long long)(ky - 18) * L.stride + (kx - 18);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int i = lane + 64 * k;
-            const int r = i / kWinDwords, d = i - r * kWinDwords;
-            if (i < kBlurW * kWinDwords) win[i] = load_u32(bsrc + (long long)r * L.stride + 4 * d);
-        }
-    }
+    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
 
-    // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc, four pixels per
-    // v_dot4_u32_u8.  m10 = sum u*I = sum (u+15)*I - 15*sum I,  m01 = sum v*I.  Row v of the disc is read as the
-    // nine dwords starting at column kx-17; bytes outside the disc have weight 0.
-    int m10 = 0, m01 = 0;
-    {
-        const uint8_t* csrc = pyr + fo + (long long)(ky - kHalfPatch) * L.stride + (kx - 17);
+    // lane constants: window dwords i = lane + 64k -> (row, byte), disc dwords i = lane + 64k -> (row, byte, weights)
+    uint32_t wrow[6], wcol[6];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int i = lane + 64 * k;
-            if (i < 31 * 9) {
-                const int rr = i / 9, d = i - rr * 9;
-                const int v = rr - kHalfPatch, av = v < 0 ? -v : v;
-                const uint32_t px = load_u32(csrc + (long long)rr * L.stride + 4 * d);
-                const uint32_t su = __builtin_amdgcn_udot4(px, c_ic.wu[av][d], 0u, false);
-                const uint32_t sm = __builtin_amdgcn_udot4(px, c_ic.wm[av][d], 0u, false);
+    for (int k = 0; k < 6; ++k) { const uint32_t i = lane + 64 * k; wrow[k] = i / kWinDwords; wcol[k] = 4 * (i - wrow[k] * kWinDwords); }
+    uint32_t crow[5], ccol[5], cwu[5], cwm[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t i = min(lane + 64 * k, 31 * 9 - 1);
+        crow[k] = i / 9; ccol[k] = 4 * (i - crow[k] * 9);
+        const int v = (int)crow[k] - kHalfPatch, av = v < 0 ? -v : v;
+        const bool live = lane + 64 * k < 31 * 9;
+        cwu[k] = live ? c_ic.wu[av][ccol[k] >> 2] : 0u;
+        cwm[k] = live ? c_ic.wm[av][ccol[k] >> 2] : 0u;
+    }
+    float4 pat[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pat[g] = reinterpret_cast<const float4*>(c_pattern_f.v)[g * 64 + lane];
+
+    for (int q = 0; q < kKpPerWave; ++q) {
+        const int slot = slot0 + q;
+        // locate (level, index) of this slot and the output offset of the level
+        int level = -1, idx = 0, outOff = 0, total = 0;
+        for (int l = 0; l < nlevels; ++l) {
+            const int cnt = lvlcnt[frame * nlevels + l];
+            const int o = lv[l].kp_offset;
+            if (slot >= o && slot < o + lv[l].kp_cap) { level = l; idx = slot - o; outOff = total; }
+            total += cnt;
+        }
+        if (slot == 0 && lane == 0) ocount[frame] = total;
+        if (level < 0) continue;
+        if (idx >= lvlcnt[frame * nlevels + level]) continue;
+        if (outOff + idx >= cap_per_frame) continue;
+        const DevLevel& L = lv[level];
+        const uint32_t key = lvlkp[(unsigned long long)frame * kp_total + L.kp_offset + idx];
+        const int kx = (int)(key >> 20) + kMinBorder, ky = (int)((key >> 8) & 0xFFF) + kMinBorder;
+        const int resp = (int)(key & 0xFF);
+        const uint32_t stride = (uint32_t)L.stride;
+        const unsigned long long fo = (unsigned long long)frame * pyr_bytes + L.roi;
+
+        wave_sync();        // the previous keypoint's tests have read the window
+        // blurred window rows ky-18..ky+18, bytes kx-18..kx+21 (the last three are not used)
+        {
+            const uint8_t* bsrc = blr + fo + (long long)(ky - 18) * L.stride + (kx - 18);
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k < 5 || lane + 64 * k < kBlurW * kWinDwords) win[lane + 64 * k] = load_u32(bsrc + (__umul24(wrow[k], stride) + wcol[k]));
+        }
+
+        // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc, four pixels per
+        // v_dot4_u32_u8.  m10 = sum u*I = sum (u+15)*I - 15*sum I,  m01 = sum v*I.  Row v of the disc is read as the
+        // nine dwords starting at column kx-17; bytes outside the disc have weight 0.
+        int m10 = 0, m01 = 0;
+        {
+            const uint8_t* csrc = pyr + fo + (long long)(ky - kHalfPatch) * L.stride + (kx - 17);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t px = load_u32(csrc + (__umul24(crow[k], stride) + ccol[k]));
+                const uint32_t su = __builtin_amdgcn_udot4(px, cwu[k], 0u, false);
+                const uint32_t sm = __builtin_amdgcn_udot4(px, cwm[k], 0u, false);
                 m10 += (int)su - 15 * (int)sm;
-                m01 += v * (int)sm;
+                m01 += ((int)crow[k] - kHalfPatch) * (int)sm;
             }
         }
-    }
-    for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
+        for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // computeOrbDescriptor (src/ORBextractor.cc:107-146)
-    constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.0); // (float)(CV_PI/180.f)
-    const float ang = __fmul_rn(angle, factorPI);
-    double sd, cd;
-    sincos_0_2pi((double)ang, sd, cd);
-    const float a = (float)cd, b = (float)sd;
-    const size_t orow = (size_t)frame * cap_per_frame + outOff + idx;
-    unsigned long long* dout = reinterpret_cast<unsigned long long*>(odesc + orow * 32);
-    wave_sync();
-    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
-    // cvRound by adding 1.5 * 2^23: the low bits of the sum's encoding are the rounded integer (ties to even)
-    constexpr float kMagic = 12582912.f;
-    constexpr uint32_t kBias = 0x4B400000u;
-    const float4* pf = reinterpret_cast<const float4*>(c_pattern_f.v);
+        // computeOrbDescriptor (src/ORBextractor.cc:107-146)
+        constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.0); // (float)(CV_PI/180.f)
+        const float ang = __fmul_rn(angle, factorPI);
+        double sd, cd;
+        sincos_0_2pi((double)ang, sd, cd);
+        const float a = (float)cd, b = (float)sd;
+        const size_t orow = (size_t)frame * cap_per_frame + outOff + idx;
+        unsigned long long* dout = reinterpret_cast<unsigned long long*>(odesc + orow * 32);
+        wave_sync();
+        // cvRound by adding 1.5 * 2^23: the low bits of the sum's encoding are the rounded integer (ties to even)
+        constexpr float kMagic = 12582912.f;
+        constexpr uint32_t kBias = 0x4B400000u;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4 pt = pf[g * 64 + lane];
-        const uint32_t r0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)), kMagic)) - kBias;
-        const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)), kMagic)) - kBias;
-        const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)), kMagic)) - kBias;
-        const uint32_t c1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)), kMagic)) - kBias;
-        const int t0 = wb[(int)(18 + r0) * (4 * kWinDwords) + (int)(18 + c0)];
-        const int t1 = wb[(int)(18 + r1) * (4 * kWinDwords) + (int)(18 + c1)];
-        const unsigned long long bits = __ballot(t0 < t1);
-        if (lane == 0) dout[g] = bits;
-    }
-    if (lane == 0) {
-        orbx_keypoint kp;
-        kp.x = (float)kx; kp.y = (float)ky;
-        if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }
-        kp.size = L.kp_size;
-        kp.angle = angle;
-        kp.response = (float)resp;
-        kp.octave = level;
-        kp.class_id = -1;
-        okp[orow] = kp;
+        for (int g = 0; g < 4; ++g) {
+            const float4 pt = pat[g];
+            const uint32_t r0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)), kMagic)) - kBias;
+            const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)), kMagic)) - kBias;
+            const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)), kMagic)) - kBias;
+            const uint32_t c1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)), kMagic)) - kBias;
+            const int t0 = wb[(int)(18 + r0) * (4 * kWinDwords) + (int)(18 + c0)];
+            const int t1 = wb[(int)(18 + r1) * (4 * kWinDwords) + (int)(18 + c1)];
+            const unsigned long long bits = __ballot(t0 < t1);
+            if (lane == 0) dout[g] = bits;
+        }
+        if (lane == 0) {
+            orbx_keypoint kp;
+            kp.x = (float)kx; kp.y = (float)ky;
+            if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }
+            kp.size = L.kp_size;
+            kp.angle = angle;
+            kp.response = (float)resp;
+            kp.octave = level;
+            kp.class_id = -1;
+            okp[orow] = kp;
+        }
     }
 }
 
@@ -1051,15 +1096,15 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[0], st));
     {
         const DevLevel& L0 = ex->hlv[0];
-        dim3 grid((L0.cpr * L0.h + 255) / 256, B);
+        dim3 grid(frame_chunk_grid((L0.cpr * L0.h + 255) / 256, B));
         hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
-                           ex->d_pyr, (unsigned long long)G.pyr_bytes, L0);
+                           ex->d_pyr, (unsigned long long)G.pyr_bytes, L0, B);
         for (int l = 1; l < G.nlevels; ++l) {
             const DevLevel& D = ex->hlv[l];
             if (D.fast_resize) {
-                dim3 g2((D.gpr * ((D.h + kResizeRows - 1) / kResizeRows) + 255) / 256, B);
+                dim3 g2(frame_chunk_grid((D.gpr * ((D.h + kResizeRows - 1) / kResizeRows) + 255) / 256, B));
                 hipLaunchKernelGGL(k_resize, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
-                                   ex->d_ry, ex->d_rga, ex->d_rgb);
+                                   ex->d_ry, ex->d_rga, ex->d_rgb, B);
             } else {
                 dim3 g2((D.w + 255) / 256, (D.h + 3) / 4, B);
                 hipLaunchKernelGGL(k_resize_generic, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
@@ -1074,15 +1119,15 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
     {
         const int nc = (int)G.cells.size();
-        dim3 grid((nc + 3) / 4, B);
+        dim3 grid(frame_chunk_grid((nc + 3) / 4, B));
         if (G.max_cell_dim <= kSmallCellDim)
             hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 48, kSmallCellDim + 2>), grid, dim3(256), 0, st, ex->d_pyr,
                                (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total, ex->d_cellcnt, nc,
-                               ex->params.ini_th_fast, ex->params.min_th_fast);
+                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
         else
             hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2>), grid, dim3(256), 0, st, ex->d_pyr,
                                (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total, ex->d_cellcnt, nc,
-                               ex->params.ini_th_fast, ex->params.min_th_fast);
+                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
     {
@@ -1095,14 +1140,15 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
     {
-        dim3 gblur((ex->max_blur_threads + 255) / 256, G.nlevels, B);
+        const int bpl = (ex->max_blur_threads + 255) / 256;
+        dim3 gblur(frame_chunk_grid((unsigned)(bpl * G.nlevels), B));
         if (ex->params.blur_rounding)
-            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv);
+            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels, bpl, B);
         else
-            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv);
-        dim3 grid((G.kp_total + 3) / 4, B);
+            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels, bpl, B);
+        dim3 grid(frame_chunk_grid((G.kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), B));
         hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels,
-                           ex->d_lvlkp, G.kp_total, ex->d_lvlcnt, d_kps, d_desc, d_counts, cap_per_frame);
+                           ex->d_lvlkp, G.kp_total, ex->d_lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
     HIP_CHECK(hipGetLastError());
