@@ -975,6 +975,7 @@ struct orbx_extractor {
     size_t oct_lds = 0;
     int last_frames = 0;
     bool profiling = false;
+
     hipEvent_t ev[ORBX_STAGE_COUNT + 1] = {};
     float stage_ms[ORBX_STAGE_COUNT] = {};
 };
@@ -1081,6 +1082,84 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     delete ex;
 }
 
+// All kernels of frames [f0, f0 + B) of a batch, on stream st.
+static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool prof, const uint8_t* d_images, ptrdiff_t row_stride,
+                         ptrdiff_t frame_stride, orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap_per_frame)
+{
+    const Geometry& G = ex->geo;
+    // per-frame arrays of this range
+    d_images += (ptrdiff_t)f0 * frame_stride;
+    d_kps += (size_t)f0 * cap_per_frame; d_desc += (size_t)f0 * cap_per_frame * 32; d_counts += f0;
+    uint8_t* const pyr = ex->d_pyr + (size_t)f0 * G.pyr_bytes;
+    uint8_t* const blur = ex->d_blur + (size_t)f0 * G.pyr_bytes;
+    uint32_t* const cand = ex->d_cand + (size_t)f0 * G.cand_total;
+    uint16_t* const cellcnt = ex->d_cellcnt + (size_t)f0 * G.cells.size();
+    uint32_t* const keys = ex->d_keys + (size_t)f0 * ex->key_total;
+    uint16_t* const nodeof = ex->d_nodeof + (size_t)f0 * ex->key_total;
+    uint32_t* const lvlkp = ex->d_lvlkp + (size_t)f0 * G.kp_total;
+    int32_t* const lvlcnt = ex->d_lvlcnt + (size_t)f0 * G.nlevels;
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[0], st));
+    {
+        const DevLevel& L0 = ex->hlv[0];
+        dim3 grid(frame_chunk_grid((L0.cpr * L0.h + 255) / 256, B));
+        hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
+                           pyr, (unsigned long long)G.pyr_bytes, L0, B);
+        for (int l = 1; l < G.nlevels; ++l) {
+            const DevLevel& D = ex->hlv[l];
+            if (D.fast_resize) {
+                dim3 g2(frame_chunk_grid((D.gpr * ((D.h + kResizeRows - 1) / kResizeRows) + 255) / 256, B));
+                hipLaunchKernelGGL(k_resize, g2, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
+                                   ex->d_ry, ex->d_rga, ex->d_rgb, B);
+            } else {
+                dim3 g2((D.w + 255) / 256, (D.h + 3) / 4, B);
+                hipLaunchKernelGGL(k_resize_generic, g2, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
+                                   ex->d_rx, ex->d_ry);
+            }
+        }
+        if (ex->generic_levels) {               // the generic resize writes no frame pixels
+            dim3 gb((ex->max_border_threads + 255) / 256, G.nlevels, B);
+            hipLaunchKernelGGL(k_borders, gb, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, kFrameFill, 1, 2);
+        }
+    }
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
+    {
+        const int nc = (int)G.cells.size();
+        dim3 grid(frame_chunk_grid((nc + 3) / 4, B));
+        if (G.max_cell_dim <= kSmallCellDim)
+            hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 48, kSmallCellDim + 2>), grid, dim3(256), 0, st, pyr,
+                               (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, cand, G.cand_total, cellcnt, nc,
+                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
+        else
+            hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2>), grid, dim3(256), 0, st, pyr,
+                               (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, cand, G.cand_total, cellcnt, nc,
+                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
+    }
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
+    {
+        // frame is the fast grid index: consecutive workgroups go to different XCDs, so every XCD gets an equal
+        // share of each level (a level-major order would put all level-0 quadtrees, the largest, on one XCD)
+        dim3 grid(B, G.nlevels);
+        hipLaunchKernelGGL(k_octree, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, cand, G.cand_total,
+                           cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp,
+                           G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL);
+    }
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
+    {
+        const int bpl = (ex->max_blur_threads + 255) / 256;
+        dim3 gblur(frame_chunk_grid((unsigned)(bpl * G.nlevels), B));
+        if (ex->params.blur_rounding)
+            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels, bpl, B);
+        else
+            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels, bpl, B);
+        dim3 grid(frame_chunk_grid((G.kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), B));
+        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels,
+                           lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B);
+    }
+    if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
+    HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
 int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdiff_t row_stride, ptrdiff_t frame_stride,
                               int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap_per_frame,
                               void* stream)
@@ -1089,71 +1168,10 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     if (n_frames < 1 || n_frames > ex->max_batch) { set_error("n_frames outside [1, max_batch]"); return ORBX_ERR_BAD_ARG; }
     if (row_stride < ex->geo.width || cap_per_frame < 1) { set_error("row_stride < width or cap_per_frame < 1"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipSetDevice(ex->device));
-    hipStream_t st = (hipStream_t)stream;
-    const Geometry& G = ex->geo;
-    const int B = n_frames;
-    const bool prof = ex->profiling;
-    if (prof) HIP_CHECK(hipEventRecord(ex->ev[0], st));
-    {
-        const DevLevel& L0 = ex->hlv[0];
-        dim3 grid(frame_chunk_grid((L0.cpr * L0.h + 255) / 256, B));
-        hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
-                           ex->d_pyr, (unsigned long long)G.pyr_bytes, L0, B);
-        for (int l = 1; l < G.nlevels; ++l) {
-            const DevLevel& D = ex->hlv[l];
-            if (D.fast_resize) {
-                dim3 g2(frame_chunk_grid((D.gpr * ((D.h + kResizeRows - 1) / kResizeRows) + 255) / 256, B));
-                hipLaunchKernelGGL(k_resize, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
-                                   ex->d_ry, ex->d_rga, ex->d_rgb, B);
-            } else {
-                dim3 g2((D.w + 255) / 256, (D.h + 3) / 4, B);
-                hipLaunchKernelGGL(k_resize_generic, g2, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
-                                   ex->d_rx, ex->d_ry);
-            }
-        }
-        if (ex->generic_levels) {               // the generic resize writes no frame pixels
-            dim3 gb((ex->max_border_threads + 255) / 256, G.nlevels, B);
-            hipLaunchKernelGGL(k_borders, gb, dim3(256), 0, st, ex->d_pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, kFrameFill, 1, 2);
-        }
-    }
-    if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
-    {
-        const int nc = (int)G.cells.size();
-        dim3 grid(frame_chunk_grid((nc + 3) / 4, B));
-        if (G.max_cell_dim <= kSmallCellDim)
-            hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 48, kSmallCellDim + 2>), grid, dim3(256), 0, st, ex->d_pyr,
-                               (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total, ex->d_cellcnt, nc,
-                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
-        else
-            hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2>), grid, dim3(256), 0, st, ex->d_pyr,
-                               (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total, ex->d_cellcnt, nc,
-                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
-    }
-    if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
-    {
-        // frame is the fast grid index: consecutive workgroups go to different XCDs, so every XCD gets an equal
-        // share of each level (a level-major order would put all level-0 quadtrees, the largest, on one XCD)
-        dim3 grid(B, G.nlevels);
-        hipLaunchKernelGGL(k_octree, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, ex->d_cand, G.cand_total,
-                           ex->d_cellcnt, (int)G.cells.size(), ex->d_keys, ex->d_nodeof, ex->key_total, ex->d_lvlkp,
-                           G.kp_total, ex->d_lvlcnt, G.nlevels, ex->NCmax, ex->KL);
-    }
-    if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
-    {
-        const int bpl = (ex->max_blur_threads + 255) / 256;
-        dim3 gblur(frame_chunk_grid((unsigned)(bpl * G.nlevels), B));
-        if (ex->params.blur_rounding)
-            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels, bpl, B);
-        else
-            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels, bpl, B);
-        dim3 grid(frame_chunk_grid((G.kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), B));
-        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels,
-                           ex->d_lvlkp, G.kp_total, ex->d_lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B);
-    }
-    if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
-    HIP_CHECK(hipGetLastError());
-    ex->last_frames = B;
-    return ORBX_OK;
+    const int rc = launch_frames(ex, (hipStream_t)stream, 0, n_frames, ex->profiling, d_images, row_stride, frame_stride, d_kps, d_desc,
+                                 d_counts, cap_per_frame);
+    if (rc == ORBX_OK) ex->last_frames = n_frames;
+    return rc;
 }
 
 static int ensure_staging(orbx_extractor* ex)
