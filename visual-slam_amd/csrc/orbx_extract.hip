@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 // from the unblurred level, the 37x37 window of the blurred level that the rotated pattern can reach is
 // staged in LDS, and the 256 binary tests read it there.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBlurW = 37, kWinDwords = 10;     // window rows are 40 bytes in LDS
+constexpr int kBlurW = 37, kWinChunks = 4;      // window rows are four 16-byte chunks in LDS, aligned as in memory
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -775,19 +775,19 @@ __device__ __forceinline__ void sincos_0_2pi(double x, double& sn, double& cs)
     cs = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
 }
 
-// Byte weights of the intensity-centroid sums for the nine aligned dwords (patch columns 4..39) of a
-// disc row |v|: wu = u + 15 inside the disc (u = column - 21), wm = 1 inside the disc, 0 outside.
-struct IcTable { uint32_t wu[16][9]; uint32_t wm[16][9]; };
+// Byte weights of the intensity-centroid sums for the eight dwords of a disc row |v| read from column u = -16:
+// wu = u + 16 inside the disc, wm = 1 inside the disc, 0 outside.
+struct IcTable { uint32_t wu[16][8]; uint32_t wm[16][8]; };
 constexpr IcTable make_ic_table()
 {
     constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     IcTable t{};
     for (int v = 0; v < 16; ++v)
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < 8; ++i) {
             uint32_t wu = 0, wm = 0;
             for (int b = 0; b < 4; ++b) {
-                const int u = 4 + 4 * i + b - 21;
-                if (u >= -um[v] && u <= um[v]) { wu |= (uint32_t)(u + 15) << (8 * b); wm |= 1u << (8 * b); }
+                const int u = 4 * i + b - 16;
+                if (u >= -um[v] && u <= um[v]) { wu |= (uint32_t)(u + 16) << (8 * b); wm |= 1u << (8 * b); }
             }
             t.wu[v][i] = wu; t.wm[v][i] = wm;
         }
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
                                                   orbx_keypoint* __restrict__ okp, uint8_t* __restrict__ odesc,
                                                   int32_t* __restrict__ ocount, int cap_per_frame, int n_frames)
 {
-    __shared__ __align__(16) uint32_t s_win[4][kBlurW * kWinDwords + 6];
+    __shared__ __align__(16) uint4 s_win[4][kBlurW * kWinChunks + 1];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // slot arithmetic stays scalar
@@ -827,71 +827,96 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     if (!frame_chunk(blockIdx.x, (kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), n_frames, frame, chunk)) return;
     const int slot0 = ((int)chunk * 4 + wave) * kKpPerWave;
     if (slot0 >= kp_total) return;
-    uint32_t* win = s_win[wave];
+    uint4* win = s_win[wave];
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
 
-    // lane constants: window dwords i = lane + 64k -> (row, byte), disc dwords i = lane + 64k -> (row, byte, weights)
-    uint32_t wrow[6], wcol[6];
+    // lane constants.  Window: 16-byte chunk l = lane, lane + 64 of the 37 x 3 chunks -> (row, byte).  Disc: lane
+    // 2*row + half reads 16 bytes of disc row `row` from column -16 + 16*half, with the weights of its four dwords.
+    uint32_t wrow[3], wcol[3];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { const uint32_t i = lane + 64 * k; wrow[k] = i / kWinDwords; wcol[k] = 4 * (i - wrow[k] * kWinDwords); }
-    uint32_t crow[5], ccol[5], cwu[5], cwm[5];
+    for (int k = 0; k < 3; ++k) { const uint32_t l = min(lane + 64 * k, kBlurW * kWinChunks - 1); wrow[k] = l / kWinChunks; wcol[k] = 16 * (l - wrow[k] * kWinChunks); }
+    const bool disc_lane = lane < 2 * kPatch;
+    const int crow = min(lane >> 1, kPatch - 1), chalf = lane & 1;
+    const int cv = crow - kHalfPatch;
+    uint32_t cwu[4], cwm[4];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const uint32_t i = min(lane + 64 * k, 31 * 9 - 1);
-        crow[k] = i / 9; ccol[k] = 4 * (i - crow[k] * 9);
-        const int v = (int)crow[k] - kHalfPatch, av = v < 0 ? -v : v;
-        const bool live = lane + 64 * k < 31 * 9;
-        cwu[k] = live ? c_ic.wu[av][ccol[k] >> 2] : 0u;
-        cwm[k] = live ? c_ic.wm[av][ccol[k] >> 2] : 0u;
+    for (int k = 0; k < 4; ++k) {
+        cwu[k] = disc_lane ? c_ic.wu[cv < 0 ? -cv : cv][4 * chalf + k] : 0u;
+        cwm[k] = disc_lane ? c_ic.wm[cv < 0 ? -cv : cv][4 * chalf + k] : 0u;
     }
     float4 pat[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) pat[g] = reinterpret_cast<const float4*>(c_pattern_f.v)[g * 64 + lane];
 
-    for (int q = 0; q < kKpPerWave; ++q) {
-        const int slot = slot0 + q;
-        // locate (level, index) of this slot and the output offset of the level
-        int level = -1, idx = 0, outOff = 0, total = 0;
-        for (int l = 0; l < nlevels; ++l) {
-            const int cnt = lvlcnt[frame * nlevels + l];
-            const int o = lv[l].kp_offset;
-            if (slot >= o && slot < o + lv[l].kp_cap) { level = l; idx = slot - o; outOff = total; }
-            total += cnt;
+    // (level, index, output row) of the wave's slots and their keys, all scalar
+    int jlevel[kKpPerWave], jidx[kKpPerWave], jout[kKpPerWave];
+#pragma unroll
+    for (int q = 0; q < kKpPerWave; ++q) { jlevel[q] = -1; jidx[q] = 0; jout[q] = 0; }
+    int total = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const int cnt = lvlcnt[frame * nlevels + l];
+        const int o = lv[l].kp_offset;
+#pragma unroll
+        for (int q = 0; q < kKpPerWave; ++q) {
+            const int i = slot0 + q - o;
+            if (i >= 0 && i < cnt && total + i < cap_per_frame) { jlevel[q] = l; jidx[q] = i; jout[q] = total + i; }
         }
-        if (slot == 0 && lane == 0) ocount[frame] = total;
-        if (level < 0) continue;
-        if (idx >= lvlcnt[frame * nlevels + level]) continue;
-        if (outOff + idx >= cap_per_frame) continue;
-        const DevLevel& L = lv[level];
-        const uint32_t key = lvlkp[(unsigned long long)frame * kp_total + L.kp_offset + idx];
-        const int kx = (int)(key >> 20) + kMinBorder, ky = (int)((key >> 8) & 0xFFF) + kMinBorder;
-        const int resp = (int)(key & 0xFF);
+        total += cnt;
+    }
+    if (slot0 == 0 && lane == 0) ocount[frame] = total;
+    uint32_t jkey[kKpPerWave];
+#pragma unroll
+    for (int q = 0; q < kKpPerWave; ++q)
+        jkey[q] = jlevel[q] >= 0 ? lvlkp[(unsigned long long)frame * kp_total + lv[jlevel[q]].kp_offset + jidx[q]] : 0u;
+
+    // The loads of keypoint q+1 are issued before the arithmetic of keypoint q.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    struct Fetched { u32x4 w0, w1, w2, d; };
+    auto fetch = [&](int q, Fetched& f) __attribute__((always_inline)) {
+        if (jlevel[q] < 0) return;
+        const DevLevel& L = lv[jlevel[q]];
+        const int kx = (int)(jkey[q] >> 20) + kMinBorder, ky = (int)((jkey[q] >> 8) & 0xFFF) + kMinBorder;
         const uint32_t stride = (uint32_t)L.stride;
         const unsigned long long fo = (unsigned long long)frame * pyr_bytes + L.roi;
-
-        wave_sync();        // the previous keypoint's tests have read the window
-        // blurred window rows ky-18..ky+18, bytes kx-18..kx+21 (the last three are not used)
-        {
-            const uint8_t* bsrc = blr + fo + (long long)(ky - 18) * L.stride + (kx - 18);
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (k < 5 || lane + 64 * k < kBlurW * kWinDwords) win[lane + 64 * k] = load_u32(bsrc + (__umul24(wrow[k], stride) + wcol[k]));
+        // blurred window rows ky-18..ky+18, the four aligned 16-byte chunks from the one holding column kx-18
+        // (ROI rows are 32-byte aligned)
+        const uint8_t* bsrc = blr + fo + (long long)(ky - 18) * L.stride + ((kx - 18) & ~15);
+        f.w0 = *reinterpret_cast<const u32x4*>(bsrc + (__umul24(wrow[0], stride) + wcol[0]));
+        f.w1 = *reinterpret_cast<const u32x4*>(bsrc + (__umul24(wrow[1], stride) + wcol[1]));
+        if (lane + 128 < kBlurW * kWinChunks) f.w2 = *reinterpret_cast<const u32x4*>(bsrc + (__umul24(wrow[2], stride) + wcol[2]));
+        // disc rows ky-15..ky+15 of the unblurred level, bytes kx-16..kx+15
+        const uint8_t* csrc = pyr + fo + (long long)(ky - kHalfPatch) * L.stride + (kx - 16);
+        if (disc_lane) {
+            const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(csrc + (__umul24((uint32_t)crow, stride) + 16u * (uint32_t)chalf));
+            f.d = u32x4{t.x, t.y, t.z, t.w};
         }
+    };
+    auto process = [&](int q, const Fetched& f) __attribute__((always_inline)) {
+        if (jlevel[q] < 0) return;
+        const int level = jlevel[q];
+        const DevLevel& L = lv[level];
+        const int kx = (int)(jkey[q] >> 20) + kMinBorder, ky = (int)((jkey[q] >> 8) & 0xFFF) + kMinBorder;
+        const int resp = (int)(jkey[q] & 0xFF);
+        wave_sync();        // the previous keypoint's tests have read the window
+        u32x4* winv = reinterpret_cast<u32x4*>(win);
+        winv[lane] = f.w0;
+        winv[lane + 64] = f.w1;
+        if (lane + 128 < kBlurW * kWinChunks) winv[lane + 128] = f.w2;
+        const int wshift = (kx - 18) & 15;
 
         // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc, four pixels per
-        // v_dot4_u32_u8.  m10 = sum u*I = sum (u+15)*I - 15*sum I,  m01 = sum v*I.  Row v of the disc is read as the
-        // nine dwords starting at column kx-17; bytes outside the disc have weight 0.
+        // v_dot4_u32_u8.  m10 = sum u*I = sum (u+16)*I - 16*sum I,  m01 = sum v*I; bytes outside the disc have weight 0.
         int m10 = 0, m01 = 0;
-        {
-            const uint8_t* csrc = pyr + fo + (long long)(ky - kHalfPatch) * L.stride + (kx - 17);
+        if (disc_lane) {
+            const uint32_t px[4] = {f.d[0], f.d[1], f.d[2], f.d[3]};
+            uint32_t su = 0, sm = 0;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const uint32_t px = load_u32(csrc + (__umul24(crow[k], stride) + ccol[k]));
-                const uint32_t su = __builtin_amdgcn_udot4(px, cwu[k], 0u, false);
-                const uint32_t sm = __builtin_amdgcn_udot4(px, cwm[k], 0u, false);
-                m10 += (int)su - 15 * (int)sm;
-                m01 += ((int)crow[k] - kHalfPatch) * (int)sm;
+            for (int k = 0; k < 4; ++k) {
+                su = __builtin_amdgcn_udot4(px[k], cwu[k], su, false);
+                sm = __builtin_amdgcn_udot4(px[k], cwm[k], sm, false);
             }
+            m10 = (int)su - 16 * (int)sm;
+            m01 = cv * (int)sm;
         }
         for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
         const float angle = fast_atan2_deg((float)m01, (float)m10);
@@ -902,7 +927,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         double sd, cd;
         sincos_0_2pi((double)ang, sd, cd);
         const float a = (float)cd, b = (float)sd;
-        const size_t orow = (size_t)frame * cap_per_frame + outOff + idx;
+        const size_t orow = (size_t)frame * cap_per_frame + jout[q];
         unsigned long long* dout = reinterpret_cast<unsigned long long*>(odesc + orow * 32);
         wave_sync();
         // cvRound by adding 1.5 * 2^23: the low bits of the sum's encoding are the rounded integer (ties to even)
@@ -915,8 +940,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)), kMagic)) - kBias;
             const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)), kMagic)) - kBias;
             const uint32_t c1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)), kMagic)) - kBias;
-            const int t0 = wb[(int)(18 + r0) * (4 * kWinDwords) + (int)(18 + c0)];
-            const int t1 = wb[(int)(18 + r1) * (4 * kWinDwords) + (int)(18 + c1)];
+            const int t0 = wb[(int)(18 + r0) * (16 * kWinChunks) + (int)(18 + c0) + wshift];
+            const int t1 = wb[(int)(18 + r1) * (16 * kWinChunks) + (int)(18 + c1) + wshift];
             const unsigned long long bits = __ballot(t0 < t1);
             if (lane == 0) dout[g] = bits;
         }
@@ -931,7 +956,14 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             kp.class_id = -1;
             okp[orow] = kp;
         }
-    }
+    };
+    static_assert(kKpPerWave == 4, "the schedule below is written out for four keypoints");
+    Fetched fa, fb;
+    fetch(0, fa);
+    fetch(1, fb); process(0, fa);
+    fetch(2, fa); process(1, fb);
+    fetch(3, fb); process(2, fa);
+    process(3, fb);
 }
 
 } // namespace
