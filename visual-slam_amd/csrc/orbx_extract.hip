@@ -352,26 +352,25 @@ __device__ __forceinline__ s16x2 pair16(uint32_t w0, uint32_t w1, uint32_t w2)
 }
 
 // Necessary condition for two horizontally adjacent pixels at once (16-bit packed lanes): an arc of 9
-// ring pixels holds one pixel of every antipodal pair, so a corner needs, for each of the four
-// even pairs (0,8) (2,10) (4,12) (6,14), one member darker than v-t -- or, for a bright corner, brighter
-// than v+t.  Returns max(min_k max(d_k,d_k+8), -max_k min(d_k,d_k+8)) per lane; a corner needs > t.
+// ring pixels holds one pixel of every antipodal pair, so a dark corner needs, in each of the four even pairs
+// (0,8) (2,10) (4,12) (6,14), one member below v - t, that is v - max_k min(p_k, p_k+8) > t; a bright corner needs
+// min_k max(p_k, p_k+8) - v > t.  Returns the larger of the two margins per lane; a corner needs > t.
 template <int J0>
-__device__ __forceinline__ uint32_t fast_pretest(const uint32_t (&m3)[3], const uint32_t (&m2)[3], const uint32_t (&c)[3],
-                                                 const uint32_t (&p2)[3], const uint32_t (&p3)[3])
+__device__ __forceinline__ s16x2 fast_pretest(const uint32_t (&m3)[3], const uint32_t (&m2)[3], const uint32_t (&c)[3],
+                                              const uint32_t (&p2)[3], const uint32_t (&p3)[3])
 {
     const s16x2 v = pair16<3 + J0>(c[0], c[1], c[2]);
-    const s16x2 d0 = v - pair16<3 + J0>(p3[0], p3[1], p3[2]);    // ( 0,+3)
-    const s16x2 d8 = v - pair16<3 + J0>(m3[0], m3[1], m3[2]);    // ( 0,-3)
-    const s16x2 d4 = v - pair16<6 + J0>(c[0], c[1], c[2]);       // (+3, 0)
-    const s16x2 d12 = v - pair16<0 + J0>(c[0], c[1], c[2]);      // (-3, 0)
-    const s16x2 d2 = v - pair16<5 + J0>(p2[0], p2[1], p2[2]);    // (+2,+2)
-    const s16x2 d14 = v - pair16<1 + J0>(p2[0], p2[1], p2[2]);   // (-2,+2)
-    const s16x2 d6 = v - pair16<5 + J0>(m2[0], m2[1], m2[2]);    // (+2,-2)
-    const s16x2 d10 = v - pair16<1 + J0>(m2[0], m2[1], m2[2]);   // (-2,-2)
-    const s16x2 dark = pmin(pmin(pmax(d0, d8), pmax(d4, d12)), pmin(pmax(d2, d10), pmax(d6, d14)));
-    const s16x2 bright = pmax(pmax(pmin(d0, d8), pmin(d4, d12)), pmax(pmin(d2, d10), pmin(d6, d14)));
-    const s16x2 zero = {0, 0};
-    return as_u32(pmax(dark, zero - bright));
+    const s16x2 r0 = pair16<3 + J0>(p3[0], p3[1], p3[2]);    // ( 0,+3)
+    const s16x2 r8 = pair16<3 + J0>(m3[0], m3[1], m3[2]);    // ( 0,-3)
+    const s16x2 r4 = pair16<6 + J0>(c[0], c[1], c[2]);       // (+3, 0)
+    const s16x2 r12 = pair16<0 + J0>(c[0], c[1], c[2]);      // (-3, 0)
+    const s16x2 r2 = pair16<5 + J0>(p2[0], p2[1], p2[2]);    // (+2,+2)
+    const s16x2 r14 = pair16<1 + J0>(p2[0], p2[1], p2[2]);   // (-2,+2)
+    const s16x2 r6 = pair16<5 + J0>(m2[0], m2[1], m2[2]);    // (+2,-2)
+    const s16x2 r10 = pair16<1 + J0>(m2[0], m2[1], m2[2]);   // (-2,-2)
+    const s16x2 hi = pmax(pmax(pmin(r0, r8), pmin(r4, r12)), pmax(pmin(r2, r10), pmin(r6, r14)));
+    const s16x2 lo = pmin(pmin(pmax(r0, r8), pmax(r4, r12)), pmin(pmax(r2, r10), pmax(r6, r14)));
+    return pmax(v - hi, lo - v);
 }
 
 // number of set bits of m below the calling lane
@@ -381,9 +380,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
 }
 
 // One wavefront per cell, four cells per workgroup; no workgroup barrier anywhere.
-//   tile load -> [pass 1: packed pretest of 256 pixels per round, survivors queued -> pass 2: exact score of the
-//   queued survivors whenever the queue fills, and at the end] -> pass 3: lane r owns row r of the cell: strict
-//   local maxima among the scored pixels, threshold choice, raster-ordered emission.
+//   tile load -> per threshold attempt { [pass 1: packed pretest of 256 pixels per round, survivors queued ->
+//   pass 2: exact score of the queued survivors whenever the queue fills, and at the end] -> pass 3: strict local
+//   maxima among the corners } -> lane r owns row r of the cell: raster-ordered emission.
 // TS/TR: tile row stride (bytes) and rows, SS/SR: score tile stride and rows.
 
 template <int TS, int TR, int SS, int SR>
@@ -394,7 +393,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 {
     __shared__ __align__(16) uint8_t s_tile[4][TR * TS];
     __shared__ __align__(16) uint8_t s_score[4][SR * SS];
-    __shared__ unsigned long long s_mask[4][2][64];
+    __shared__ unsigned long long s_mask[4][64];
     // one list per cell: the scored pixels (corners at the lower threshold) found so far, then the pretest survivors
     // waiting for their score; together never more than the pixels of the cell
     constexpr int QCAP = ((TR - 6) * (TR - 6) + 7) & ~7;
@@ -411,8 +410,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + L.roi + (long long)c.y0 * L.stride + c.x0;
     uint8_t* tile = s_tile[wave];
     uint8_t* score = s_score[wave];
-    unsigned long long* mskIni = s_mask[wave][0];
-    unsigned long long* mskMin = s_mask[wave][1];
+    unsigned long long* rowmask = s_mask[wave];
     uint16_t* queue = s_queue[wave];
     const int cw = c.cw, ch = c.ch;
     const int tw = cw + 6, th = ch + 6;
@@ -426,86 +424,92 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                 *reinterpret_cast<uint4*>(tile + r * TS + 16 * j) = make_uint4(t.x, t.y, t.z, t.w);
             }
     }
-    for (int i = lane; i < (ch + 2) * (SS / 16); i += 64) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
-    mskIni[lane] = 0; mskMin[lane] = 0;
-    wave_sync();
-
-    const int lowTh = min(iniTh, minTh);
     const int gpr = (cw + 3) >> 2;                 // groups of four pixels per row (<= 15)
     const int gsh = gpr <= 8 ? 3 : 4;
     const int g = lane & ((1 << gsh) - 1);
     const int rows_per_round = 64 >> gsh;
     const int x = 4 * g;
-    const uint32_t colmask = g < gpr ? (1u << min(cw - x, 4)) - 1u : 0u;   // pixels past the cell's last column
-    int nq = 0, nsq = 0;                            // wave-uniform queue fills
-    for (int y0 = 0; y0 < ch; y0 += rows_per_round) {
-        const int y = y0 + (lane >> gsh);
-        uint32_t pm = 0;
-        if (y < ch && colmask) {
-            const uint32_t* row = reinterpret_cast<const uint32_t*>(&tile[y * TS]) + g;   // tile row y = image row y-3
-            constexpr int RS = TS / 4;
-            const uint32_t m3[3] = {row[0], row[1], row[2]};
-            const uint32_t m2[3] = {row[RS], row[RS + 1], row[RS + 2]};
-            const uint32_t cc[3] = {row[3 * RS], row[3 * RS + 1], row[3 * RS + 2]};
-            const uint32_t p2[3] = {row[5 * RS], row[5 * RS + 1], row[5 * RS + 2]};
-            const uint32_t p3[3] = {row[6 * RS], row[6 * RS + 1], row[6 * RS + 2]};
-            const uint32_t t01 = fast_pretest<0>(m3, m2, cc, p2, p3);
-            const uint32_t t23 = fast_pretest<2>(m3, m2, cc, p2, p3);
-            pm = ((int)(short)(t01 & 0xFFFFu) > lowTh ? 1u : 0u) | (((int)t01 >> 16) > lowTh ? 2u : 0u) |
-                 ((int)(short)(t23 & 0xFFFFu) > lowTh ? 4u : 0u) | (((int)t23 >> 16) > lowTh ? 8u : 0u);
-            pm &= colmask;
-        }
-        // queue the survivors of this round (wave-level compaction, one ballot per pixel slot)
-        const int idx = y * 64 + x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool on = (pm >> j) & 1u;
-            const unsigned long long m = __ballot(on);
-            if (on) queue[nsq + nq + lanes_below(m)] = (uint16_t)(idx + j);
-            nq += __popcll(m);
-        }
-        if (nq >= 192 || y0 + rows_per_round >= ch) {
-            // pass 2: exact score of the queued survivors; corners go to the score tile and the scored list
-            // (a scored entry is written at or below the slot its lane just read, so no waiting entry is overwritten)
-            wave_sync();
-            const int first = nsq;
-            for (int e0 = 0; e0 < nq; e0 += 64) {
-                const int e = e0 + lane;
-                bool keep = false;
-                int i = 0;
-                if (e < nq) {
-                    i = queue[first + e];
-                    const int yy = i >> 6, xx = i & 63;
-                    const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
-                    keep = sc >= lowTh && sc >= 1;
-                    if (keep) score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
-                }
-                const unsigned long long m = __ballot(keep);
-                if (keep) queue[nsq + lanes_below(m)] = (uint16_t)i;
-                nsq += __popcll(m);
+    // survivor mask layout: pixel 0, 2 of the lane's four in bits 0, 1 and pixel 1, 3 in bits 16, 17
+    const int npx = g < gpr ? min(cw - x, 4) : 0;                          // pixels of the lane inside the cell
+    const uint32_t colmask = (npx > 0 ? 1u : 0u) | (npx > 1 ? 1u << 16 : 0u) | (npx > 2 ? 2u : 0u) | (npx > 3 ? 2u << 16 : 0u);
+
+    // cv::FAST(cell, T, nonmax) at T = iniThFAST; only if that returns nothing, at T = minThFAST (:808-815).  Pixels
+    // scoring below T play no part at threshold T (a kept pixel beats them anyway), so each attempt scores only
+    // its own corners; nearly every cell is done after the first.
+    unsigned long long mask = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int T = max(attempt == 0 ? iniTh : minTh, 1);          // score >= T  <=>  corner at threshold T (T >= 1)
+        for (int i = lane; i < (ch + 2) * (SS / 16); i += 64) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
+        rowmask[lane] = 0;
+        wave_sync();
+        const s16x2 thr1 = {(short)(T + 1), (short)(T + 1)};
+        int nq = 0, nsq = 0;                            // wave-uniform queue fills
+        for (int y0 = 0; y0 < ch; y0 += rows_per_round) {
+            const int y = y0 + (lane >> gsh);
+            uint32_t pm = 0;
+            if (y < ch && colmask) {
+                const uint32_t* row = reinterpret_cast<const uint32_t*>(&tile[y * TS]) + g;   // tile row y = image row y-3
+                constexpr int RS = TS / 4;
+                const uint32_t m3[3] = {row[0], row[1], row[2]};
+                const uint32_t m2[3] = {row[RS], row[RS + 1], row[RS + 2]};
+                const uint32_t cc[3] = {row[3 * RS], row[3 * RS + 1], row[3 * RS + 2]};
+                const uint32_t p2[3] = {row[5 * RS], row[5 * RS + 1], row[5 * RS + 2]};
+                const uint32_t p3[3] = {row[6 * RS], row[6 * RS + 1], row[6 * RS + 2]};
+                // margin - (T + 1) is non-negative (sign bit clear) exactly for the survivors
+                const uint32_t q01 = as_u32(fast_pretest<0>(m3, m2, cc, p2, p3) - thr1);
+                const uint32_t q23 = as_u32(fast_pretest<2>(m3, m2, cc, p2, p3) - thr1);
+                pm = (((q01 & 0x80008000u) ^ 0x80008000u) >> 15) | (((q23 & 0x80008000u) ^ 0x80008000u) >> 14);
+                pm &= colmask;
             }
-            wave_sync();
-            nq = 0;
+            // queue the survivors of this round (wave-level compaction, one ballot per pixel slot)
+            const int idx = y * 64 + x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = (pm >> ((j >> 1) + 16 * (j & 1))) & 1u;
+                const unsigned long long m = __ballot(on);
+                if (on) queue[nsq + nq + lanes_below(m)] = (uint16_t)(idx + j);
+                nq += __popcll(m);
+            }
+            if (nq >= 192 || y0 + rows_per_round >= ch) {
+                // pass 2: exact score of the queued survivors; corners go to the score tile and the scored list
+                // (a scored entry is written at or below the slot its lane just read, so no waiting entry is overwritten)
+                wave_sync();
+                const int first = nsq;
+                for (int e0 = 0; e0 < nq; e0 += 64) {
+                    const int e = e0 + lane;
+                    bool keep = false;
+                    int i = 0;
+                    if (e < nq) {
+                        i = queue[first + e];
+                        const int yy = i >> 6, xx = i & 63;
+                        const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
+                        keep = sc >= T;
+                        if (keep) score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) queue[nsq + lanes_below(m)] = (uint16_t)i;
+                    nsq += __popcll(m);
+                }
+                wave_sync();
+                nq = 0;
+            }
         }
+        // pass 3: strict local maxima inside the cell among the corners, one lane per corner; row masks of the maxima
+        for (int e = lane; e < nsq; e += 64) {
+            const int i = queue[e];
+            const int yy = i >> 6, xx = i & 63;
+            const uint8_t* sp = &score[(yy + 1) * SS + xx + 1];
+            const int sc = sp[0];
+            const bool mx = sc > sp[-1] && sc > sp[1] &&
+                            sc > sp[-SS - 1] && sc > sp[-SS] && sc > sp[-SS + 1] &&
+                            sc > sp[SS - 1] && sc > sp[SS] && sc > sp[SS + 1];
+            if (mx) atomicOr(&rowmask[yy], 1ull << xx);
+        }
+        wave_sync();
+        mask = rowmask[lane];                                         // lane r owns row r (rows >= ch are empty)
+        if (__any(mask != 0ull) || max(minTh, 1) >= T) break;         // a second attempt at a threshold not below T finds nothing new
+        wave_sync();
     }
-    // pass 3: strict local maxima inside the cell among the scored pixels, one lane per scored pixel; row masks
-    // of the maxima at the two thresholds
-    const int tIni = max(iniTh, 1), tMin = max(minTh, 1);
-    for (int e = lane; e < nsq; e += 64) {
-        const int i = queue[e];
-        const int yy = i >> 6, xx = i & 63;
-        const uint8_t* sp = &score[(yy + 1) * SS + xx + 1];
-        const int sc = sp[0];
-        const bool mx = sc > sp[-1] && sc > sp[1] &&
-                        sc > sp[-SS - 1] && sc > sp[-SS] && sc > sp[-SS + 1] &&
-                        sc > sp[SS - 1] && sc > sp[SS] && sc > sp[SS + 1];
-        if (mx && sc >= tMin) atomicOr(&mskMin[yy], 1ull << xx);
-        if (mx && sc >= tIni) atomicOr(&mskIni[yy], 1ull << xx);
-    }
-    wave_sync();
-    const unsigned long long mi = mskIni[lane], mm = mskMin[lane];   // lane r owns row r (rows >= ch are empty)
-    // threshold choice (FAST at iniThFAST, and only if that finds nothing, at minThFAST) and emission
-    unsigned long long mask = __any(mi != 0ull) ? mi : mm;
     const int cnt = __popcll(mask);
     int inc = cnt;
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
