@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--contexts", type=int, default=4,
+                    help="extractor contexts per GPU, each on its own HIP stream with batch/contexts frames "
+                         "(the reference runs two extractors concurrently for stereo, src/Frame.cc:78-81)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
@@ -78,9 +81,12 @@ def main():
 
     # ------------------------------------------------------------------ extraction workload
     W, H, B = a.width, a.height, a.batch
+    C = max(1, min(a.contexts, B))
+    per = (B + C - 1) // C
     p = vsa.make_params(nfeatures=a.nfeatures, nlevels=a.nlevels)
-    ex = vsa.Extractor(p, W, H, max_batch=B, device=local)
-    cap = ex.cap
+    exs = [vsa.Extractor(p, W, H, max_batch=per, device=local) for _ in range(C)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(C)]
+    cap = exs[0].cap
     # distinct synthetic frames per rank (32 generated, tiled to the batch)
     n_unique = min(B, 32)
     uniq = np.stack([vsa.synth_frame(rank * 100000 + i, W, H) for i in range(n_unique)])
@@ -88,10 +94,16 @@ def main():
     kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
     desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     counts = torch.zeros(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
 
     def extract_step():
-        ex.extract_batch_device(frames.data_ptr(), W, W * H, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+        # one pass over the GPU's batch: context c takes frames [c*per, (c+1)*per) on its own stream
+        for c in range(C):
+            f0 = c * per
+            nf = min(per, B - f0)
+            if nf > 0:
+                exs[c].extract_batch_device(frames[f0:].data_ptr(), W, W * H, nf, kps[f0:].data_ptr(), desc[f0:].data_ptr(),
+                                            counts[f0:].data_ptr(), cap, streams[c].cuda_stream)
 
     for _ in range(a.warmup):
         extract_step()
@@ -103,13 +115,24 @@ def main():
     t_extract = max_over_ranks(time.perf_counter() - t0)
     fps = n_gpus * B * a.steps / t_extract
     mean_kp = float(counts.float().mean().item())
+    for e in exs:
+        e.close()
 
-    # per-stage device time with HIP events on the launch stream (separate steps, same workload)
+    # per-stage device time: HIP events recorded by the library on the launch stream around each stage, whole batch
+    # in one context on one stream (separate steps, same workload)
+    ex = vsa.Extractor(p, W, H, max_batch=B, device=local)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def profiled_step():
+        ex.extract_batch_device(frames.data_ptr(), W, W * H, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+
+    profiled_step()
+    torch.cuda.synchronize()
     ex.set_profiling(True)
     stage_ms = np.zeros(len(vsa.STAGES))
     prof_steps = max(3, min(a.steps, 10))
     for _ in range(prof_steps):
-        extract_step()
+        profiled_step()
         stage_ms += ex.stage_ms()
     stage_ms /= prof_steps
     ex.set_profiling(False)
@@ -133,11 +156,22 @@ def main():
     dom = max((n for n in vsa.STAGES if stage_bytes[n] > 0), key=lambda n: stage_ms[vsa.STAGES.index(n)])
     dom_ms = float(stage_ms[vsa.STAGES.index(dom)])
     achieved = stage_bytes[dom] * B / (dom_ms * 1e-3) / 1e9
+    # HBM bytes per launch of that stage's kernels, measured with rocprofv3 --pmc on this workload (tools/pmc_traffic.py)
+    traffic, traffic_src = None, None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile) and (W, H, B, a.nfeatures, a.nlevels) == (640, 480, 256, 1000, 8):
+        with open(tfile) as f:
+            tj = json.load(f)
+        if dom in tj.get("stages", {}):
+            traffic, traffic_src = tj["stages"][dom], tj.get("source")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": None,
+                "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "alg_bytes_per_launch": int(stage_bytes[dom] * B), "launch_ms": round(dom_ms, 4),
                 "pipeline_alg_bytes_per_frame": int(a_extract),
                 "pipeline_frac": round(a_extract * (fps / n_gpus) / HBM_PEAK, 4)}
 
+    ex.close()
+    stream = torch.cuda.current_stream().cuda_stream
     # ------------------------------------------------------------------ Hamming workload
     hamming = None
     if not a.no_hamming:
@@ -198,12 +232,11 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"ORBextractor {W}x{H} nFeatures={a.nfeatures} nLevels={a.nlevels} scale=1.2 ini=20 min=7, "
                                    f"{B} HBM-resident frames per GPU per step (BASELINE configs[0] shape, batched)",
-                       "frames_per_gpu_per_step": B, "mean_keypoints_per_frame": round(mean_kp, 1),
+                       "frames_per_gpu_per_step": B, "contexts_per_gpu": C, "mean_keypoints_per_frame": round(mean_kp, 1),
                        "parallelism": f"frames sharded over {n_gpus} GPU(s), no collective"},
             "roofline": roofline, "stages": stages, "hamming": hamming, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    ex.close()
     if dist is not None:
         dist.destroy_process_group()
 

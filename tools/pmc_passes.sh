@@ -6,7 +6,7 @@ set -u
 out=$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-args="--steps 2 --warmup 1 --no-cpu-baseline $*"
+args="--steps 2 --warmup 1 --no-cpu-baseline --contexts 1 $*"
 run() { # name counters...
   name=$1; shift
   timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py $args > "$out/$name.log" 2>&1 || { echo "pass $name failed"; return 1; }

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""HBM-side bytes per launch of every extraction kernel from two rocprofv3 --pmc passes over
+`bench.py --contexts 1` (one launch of a kernel covers the whole 256-frame batch):
+  pass 1: TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum   (read requests by size)
+  pass 2: TCC_EA0_WRREQ_WRITE_DRAM_32B_sum                                    (written 32-byte units)
+bytes read = 32*n32 + 64*n64 + 128*n128, bytes written = 32*units.  (FETCH_SIZE tallies gfx950's 128-byte
+requests at 64 bytes; the per-size counters do not.)  Writes profiles/traffic.json, keyed by bench.py's stages.
+usage: pmc_traffic.py <dir with the passes' counter_collection.csv> <out.json> [resize launches per step]"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+root, out = sys.argv[1], sys.argv[2]
+resizes = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+tab = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"\bk_[a-z0-9_]+", r["Kernel_Name"])
+        if m:
+            tab[m.group(0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+mean = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in tab.items()}
+kern = {}
+for k, d in mean.items():
+    rd = 32 * d.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * d.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * d.get("TCC_EA0_RDREQ_128B_sum", 0)
+    wr = 32 * d.get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", 0)
+    kern[k] = {"read_bytes": int(rd), "write_bytes": int(wr)}
+tot = lambda k, n=1: n * (kern.get(k, {}).get("read_bytes", 0) + kern.get(k, {}).get("write_bytes", 0))
+stages = {"pyramid": tot("k_level0") + tot("k_resize", resizes) + tot("k_borders"), "fast": tot("k_fast_cells"),
+          "octree": tot("k_octree"), "describe": tot("k_blur") + tot("k_describe")}
+json.dump({"source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_WRITE_DRAM_32B_sum over "
+                     "bench.py --contexts 1 (640x480, 256 frames per launch); k_resize is the mean of its launches "
+                     f"times {resizes}", "kernels_mean_per_launch": kern, "stages": stages}, open(out, "w"), indent=1)
+print(json.dumps(stages))
