@@ -15,9 +15,9 @@ extern "C" int otsim_distribute(const uint32_t* keys, int nk, int minX, int maxX
     const float hX = (float)W / nIni;
     int NC = std::max(N + 3, 4 * nIni) + 1;
     std::vector<OtNode> a(NC), b(NC);
-    std::vector<int32_t> cc(4 * NC), candPos(NC), pi(NC), cByPi(NC), keep(NC), posToCand(NC), scal(16), tmp(8);
+    std::vector<int32_t> cc(4 * NC), candPos(NC), pi(NC), cByPi(NC), keep(NC), posToCand(NC), cc2(2 * NC + 2), scal(16), tmp(8);
     std::vector<uint16_t> nodeOf(nk > 0 ? nk : 1);
-    OtShared s{a.data(), b.data(), cc.data(), candPos.data(), pi.data(), cByPi.data(), keep.data(), posToCand.data(), scal.data(), tmp.data()};
+    OtShared s{a.data(), b.data(), cc.data(), candPos.data(), pi.data(), cByPi.data(), keep.data(), posToCand.data(), reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(cc2.data()) + 7) & ~(uintptr_t)7), scal.data(), tmp.data()};
     OtMemKeys ks{keys, nodeOf.data(), nk};
     (void)W;
     return ot_distribute(s, ks, keys, H, nIni, hX, N, out, cap);

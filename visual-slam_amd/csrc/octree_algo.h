@@ -25,7 +25,7 @@
 static inline int ot_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned ot_atomic_max(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline float ot_fdiv(float a, float b) { return a / b; }
-static inline void ot_count(int* base, int idx) { base[idx] += 1; }
+static inline void ot_count(int* base, int idx) { if (idx >= 0) base[idx] += 1; }
 #else
 #define OT_DEV __device__ __forceinline__
 #define OT_TID ((int)threadIdx.x)
@@ -34,30 +34,25 @@ static inline void ot_count(int* base, int idx) { base[idx] += 1; }
 static __device__ __forceinline__ int ot_atomic_add(int* p, int v) { return atomicAdd(p, v); }
 static __device__ __forceinline__ unsigned ot_atomic_max(unsigned* p, unsigned v) { return atomicMax(p, v); }
 static __device__ __forceinline__ float ot_fdiv(float a, float b) { return __fdiv_rn(a, b); }
-// base[idx] += 1 from every calling lane.  Neighbouring keys mostly fall into the same node and quadrant, so
-// the lanes of a wave are first grouped by target (up to four groups, one LDS atomic each); what is left
-// adds on its own.  Without this the LDS serialises up to 64 same-address atomics per wave instruction.
+// base[idx] += 1 for every lane with idx >= 0.  Every lane of the wavefront must call it (idx < 0: nothing to
+// add).  Keys are stored in raster order, so neighbouring lanes mostly hit the same node and quadrant: each
+// run of equal targets adds once, with the run's length, instead of up to 64 same-address atomics.
 static __device__ __forceinline__ void ot_count(int* base, int idx)
 {
     const int lane = threadIdx.x & 63;
-    bool pending = true;
-    for (int r = 0; r < 4; ++r) {
-        const unsigned long long todo = __ballot(pending);
-        if (!todo) return;
-        const int leader = __ffsll((long long)todo) - 1;
-        const int t = __shfl(idx, leader, 64);
-        const bool mine = pending && idx == t;
-        const unsigned long long same = __ballot(mine);
-        if (lane == leader) atomicAdd(&base[t], __popcll(same));
-        if (mine) pending = false;
-    }
-    if (pending) atomicAdd(&base[idx], 1);
+    const int prev = __shfl_up(idx, 1, 64);
+    const bool head = lane == 0 || idx != prev;
+    const unsigned long long m = __ballot(head);
+    const unsigned long long above = lane == 63 ? 0ull : m >> (lane + 1);
+    const int len = above ? __ffsll((long long)above) : 64 - lane;      // lanes up to the next run
+    if (head && idx >= 0) atomicAdd(&base[idx], len);
 }
 #endif
 
 namespace orbx {
 
 constexpr uint16_t kOtDead = 0xFFFF;
+constexpr int kOtSingle = 1 << 30;   // flag on a child position: the child holds exactly one key
 
 struct OtNode {            // 16 bytes
     int16_t x0, x1, y0, y1;
@@ -75,6 +70,7 @@ struct OtShared {
     int32_t* cByPi;        // [NC] non-empty child count by processing index -> exclusive scan
     int32_t* keep;         // [NC] unsplit flag by position -> exclusive scan -> new position
     int32_t* posToCand;    // [NC] candidate index of a position (or -1)
+    int32_t* cc2;          // [NC*2] 8-byte aligned scratch: 64-bit sort keys of the fine pass
     int32_t* scal;         // [16] scalars
     int32_t* scanTmp;      // [NT/64 + 2] block-scan scratch (device)
 };
@@ -166,23 +162,24 @@ static OT_DEV void ot_for_keys(KS& ks, int tid, int nt, F&& f)
     for (int k = tid; k < ks.nk; k += nt, ++j) f(j, k);
 }
 
-// Two-phase form: `look` (loads only, returns a value) runs for four keys before `commit` (stores, atomics)
-// runs for them, so the four dependent load chains overlap instead of running back to back.
+// Two-phase form in which every thread runs the same number of rounds, so `commit` may use wavefront-wide
+// operations: `look` (loads only; returns an int, -1 meaning nothing to do) runs for four keys before `commit`
+// (stores, atomics) runs for them, and the four dependent load chains overlap instead of running back to back.
+// Past the last key commit is called with -1.
 template <class KS, class L, class C>
 static OT_DEV void ot_for_keys4(KS& ks, int tid, int nt, L&& look, C&& commit)
 {
     int j = 0;
-    for (int k = tid; k < ks.nk; k += 4 * nt, j += 4) {
-        auto v0 = look(j, k);
-        const int k1 = k + nt, k2 = k + 2 * nt, k3 = k + 3 * nt;
-        decltype(v0) v1 = v0, v2 = v0, v3 = v0;
-        if (k1 < ks.nk) v1 = look(j + 1, k1);
-        if (k2 < ks.nk) v2 = look(j + 2, k2);
-        if (k3 < ks.nk) v3 = look(j + 3, k3);
+    for (int k0 = 0; k0 < ks.nk; k0 += 4 * nt, j += 4) {
+        const int k = k0 + tid, k1 = k + nt, k2 = k + 2 * nt, k3 = k + 3 * nt;
+        const int v0 = k < ks.nk ? look(j, k) : -1;
+        const int v1 = k1 < ks.nk ? look(j + 1, k1) : -1;
+        const int v2 = k2 < ks.nk ? look(j + 2, k2) : -1;
+        const int v3 = k3 < ks.nk ? look(j + 3, k3) : -1;
         commit(j, k, v0);
-        if (k1 < ks.nk) commit(j + 1, k1, v1);
-        if (k2 < ks.nk) commit(j + 2, k2, v2);
-        if (k3 < ks.nk) commit(j + 3, k3, v3);
+        commit(j + 1, k1, v1);
+        commit(j + 2, k2, v2);
+        commit(j + 3, k3, v3);
     }
 }
 
@@ -201,7 +198,7 @@ static OT_DEV void ot_coarse_step(OtShared& s, KS& ks)
             const uint16_t p = ks.get(j, k);
             return p == kOtDead ? -1 : 4 * p + ot_quadrant(s.cur[p], ks.key(j, k));
         },
-        [&](int, int, int target) { if (target >= 0) ot_count(s.cc, target); });
+        [&](int, int, int target) { ot_count(s.cc, target); });
     OT_SYNC();
     for (int p = tid; p < n; p += nt) {
         const int* c = &s.cc[4 * p];
@@ -227,7 +224,7 @@ static OT_DEV void ot_coarse_step(OtShared& s, KS& ks)
                     ch.cnt = cnt;
                     ch.aux = (uint32_t)(seqBase + cex + before);
                     s.nxt[np] = ch;
-                    c[q] = np;
+                    c[q] = cnt == 1 ? np | kOtSingle : np;   // the key of a one-key child is parked in the child
                     nexp += cnt > 1;
                     ++before;
                 } else c[q] = -1;
@@ -242,12 +239,11 @@ static OT_DEV void ot_coarse_step(OtShared& s, KS& ks)
         [&](int j, int k) -> int {
             const uint16_t p = ks.get(j, k);
             if (p == kOtDead) return -1;
-            const int np = s.cc[4 * p + ot_quadrant(s.cur[p], ks.key(j, k))];
-            return s.nxt[np].cnt == 1 ? np | (1 << 30) : np;
+            return s.cc[4 * p + ot_quadrant(s.cur[p], ks.key(j, k))];
         },
         [&](int j, int k, int np) {
             if (np < 0) return;
-            if (np & (1 << 30)) { s.nxt[np & 0xFFFF].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
+            if (np & kOtSingle) { s.nxt[np & 0xFFFF].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
             else ks.set(j, k, (uint16_t)np);
         });
     if (tid == 0) { s.scal[OT_N] = C + nkeep; s.scal[OT_SEQ] = seqBase + C; }
@@ -273,12 +269,12 @@ static OT_DEV void ot_split_step(OtShared& s, KS& ks, int N, int fine)
     }
     OT_SYNC();
     // child key counts of every candidate
-    ot_for_keys(ks, tid, nt, [&](int j, int k) {
-        const uint16_t p = ks.get(j, k);
-        if (p == kOtDead) return;
-        const int e = s.posToCand[p];
-        ot_count(s.cc, 4 * e + ot_quadrant(s.cur[p], ks.key(j, k)));
-    });
+    ot_for_keys4(ks, tid, nt,
+        [&](int j, int k) -> int {
+            const uint16_t p = ks.get(j, k);
+            return p == kOtDead ? -1 : 4 * s.posToCand[p] + ot_quadrant(s.cur[p], ks.key(j, k));
+        },
+        [&](int, int, int target) { ot_count(s.cc, target); });
     OT_SYNC();
     // processing order
     if (!fine) {
@@ -287,18 +283,14 @@ static OT_DEV void ot_split_step(OtShared& s, KS& ks, int N, int fine)
         OT_SYNC();
     } else {
         // rank by (count desc, sequence desc): the reference sorts ascending and walks from the back (:683-684)
-        // (compact copies of count and sequence first, so the inner loop has no dependent loads)
-        for (int e = tid; e < E; e += nt) { const OtNode& a = s.cur[s.candPos[e]]; s.cByPi[e] = a.cnt; s.keep[e] = (int32_t)a.aux; }
+        // (count and sequence packed into one 64-bit sort key per candidate first: one load and one compare per pair)
+        unsigned long long* rk = reinterpret_cast<unsigned long long*>(s.cc2);
+        for (int e = tid; e < E; e += nt) { const OtNode& a = s.cur[s.candPos[e]]; rk[e] = ((unsigned long long)(uint32_t)a.cnt << 32) | a.aux; }
         OT_SYNC();
         for (int e = tid; e < E; e += nt) {
-            const int acnt = s.cByPi[e];
-            const uint32_t aseq = (uint32_t)s.keep[e];
+            const unsigned long long a = rk[e];
             int r = 0;
-            for (int m = 0; m < E; ++m) {
-                const int bcnt = s.cByPi[m];
-                const uint32_t bseq = (uint32_t)s.keep[m];
-                r += (bcnt > acnt) || (bcnt == acnt && bseq > aseq);
-            }
+            for (int m = 0; m < E; ++m) r += rk[m] > a;
             s.pi[e] = r;
         }
         OT_SYNC();
@@ -417,12 +409,15 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
     }
     if (tid == 0) { s.scal[OT_SEQ] = nIni; }
     OT_SYNC();
-    ot_for_keys(ks, tid, nt, [&](int j, int k) {
-        int r = (int)ot_fdiv((float)ot_key_x(ks.key(j, k)), hX);
-        if (r > nIni - 1) r = nIni - 1;
-        ks.set(j, k, (uint16_t)r);
-        ot_count(s.cc, r);
-    });
+    ot_for_keys4(ks, tid, nt,
+        [&](int j, int k) -> int {
+            int r = (int)ot_fdiv((float)ot_key_x(ks.key(j, k)), hX);
+            return r > nIni - 1 ? nIni - 1 : r;
+        },
+        [&](int j, int k, int r) {
+            if (r >= 0) ks.set(j, k, (uint16_t)r);
+            ot_count(s.cc, r);
+        });
     OT_SYNC();
     // drop empty roots (:571-584); a root with one key keeps it
     for (int i = tid; i < nIni; i += nt) { s.nxt[i].cnt = s.cc[i]; s.keep[i] = s.cc[i] > 0 ? 1 : 0; }

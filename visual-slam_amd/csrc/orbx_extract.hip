@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 // dense key array (cell-row-major, raster inside a cell: the reference's vToDistributeKeys order),
 // then runs the level-synchronous DistributeOctTree of octree_algo.h.
 // ---------------------------------------------------------------------------------------------
-constexpr int kOctThreads = 256;
+constexpr int kOctThreads = 256;     // more threads per quadtree were slower (512: +15 %, 1024: 2x at 640x480)
 
 // LDS layout: the node tables of OtShared (capacity NC nodes), then room for KL keys (4 B) and node ids (2 B)
 __device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads)
@@ -545,13 +545,15 @@ __device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads
     s.cByPi = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * NC;
     s.keep = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * NC;
     s.posToCand = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * NC;
+    o = (o + 7) & ~(size_t)7;
+    s.cc2 = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * 2 * NC;
     s.scal = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * 16;
     s.scanTmp = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * (nthreads / 64 + 2);
     return (o + 15) & ~(size_t)15;
 }
 size_t ot_lds_bytes(int NC, int nthreads, int KL)
 {
-    size_t o = sizeof(OtNode) * 2 * NC + sizeof(int32_t) * (4 + 5) * NC + sizeof(int32_t) * 16 + sizeof(int32_t) * (nthreads / 64 + 2);
+    size_t o = sizeof(OtNode) * 2 * NC + sizeof(int32_t) * (4 + 5) * NC + 8 + sizeof(int32_t) * 2 * NC + sizeof(int32_t) * 16 + sizeof(int32_t) * (nthreads / 64 + 2);
     o = (o + 15) & ~(size_t)15;
     return o + (size_t)KL * 6 + 16;
 }
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* _
     const uint32_t* K = keys; uint16_t* NO = nodeOf;
     if (nk <= KL) {                     // KL == 0 keeps the keys in device memory
         uint32_t* kl = reinterpret_cast<uint32_t*>(ot_mem + keyOff);
-        for (int k = threadIdx.x; k < nk; k += kOctThreads) kl[k] = keys[k];
+        for (int k = threadIdx.x; k < nk; k += blockDim.x) kl[k] = keys[k];
         K = kl;
         NO = reinterpret_cast<uint16_t*>(ot_mem + keyOff + (size_t)KL * 4);
         __syncthreads();
@@ -1064,15 +1066,14 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     }
     ex->key_total = key_off;
     ex->NCmax = std::max(ncmax + 8, 64);
-    ex->KL = std::min(8192, std::max(2048, (width * height) / 64));
+    // LDS key arrays: as many keys as leave five workgroups resident per CU (160 KB / 5 each); residency matters
+    // more than keeping the largest level's keys out of device memory (measured at 640x480: 3 resident 0.144 ms,
+    // 5 resident 0.110 ms per 256 frames).  Below 512 keys the LDS arrays are not worth having.
     {
-        // large quotas leave less LDS for keys; below 512 keys the LDS arrays are not worth having
-        const long room = 150L * 1024 - (long)ot_lds_bytes(ex->NCmax, kOctThreads, 0) - 64;
-        ex->KL = (int)std::max(0L, std::min((long)ex->KL, room / 6));
+        const long room = 31L * 1024 - (long)ot_lds_bytes(ex->NCmax, kOctThreads, 0);
+        ex->KL = (int)std::max(0L, room / 6) / 128 * 128;
         if (ex->KL < 512) ex->KL = 0;
     }
-    if (const char* e = getenv("ORBX_OCT_THREADS")) ex->oct_threads = std::max(64, std::min(kOctThreads, atoi(e) / 64 * 64));
-    if (const char* e = getenv("ORBX_OCT_KL")) ex->KL = atoi(e);
     ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads, ex->KL);
     if (ex->oct_lds > 150 * 1024) { delete ex; set_error("per-level keypoint quota too large for the quadtree working set in LDS"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ex->oct_lds));
