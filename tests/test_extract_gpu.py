@@ -18,6 +18,8 @@ CONFIGS = [
     (160, 120, 300, 2, 1.2, 20, 7, 6),       # tiny
     (321, 243, 500, 5, 1.3, 25, 9, 7),       # odd sizes, other scale
     (640, 480, 1000, 3, 2.0, 20, 7, 8),      # exact 2x decimation (INTER_AREA reroute)
+    (3840, 2160, 8000, 12, 1.2, 20, 7, 9),   # 4K stress shape: quadtree keys in device memory, 1500-keypoint quotas
+    (480, 640, 1000, 8, 1.2, 20, 7, 10),     # portrait
 ]
 
 

@@ -212,7 +212,7 @@ class Extractor:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # lib is None while the interpreter shuts down
             lib.orbx_extractor_destroy(self.h)
             self.h = None
 
@@ -283,7 +283,7 @@ class Matcher:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.orbx_matcher_destroy(self.h)
             self.h = None
 
@@ -374,7 +374,7 @@ class FrameGrid:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.orbx_grid_destroy(self.h)
             self.h = None
 
