@@ -214,6 +214,24 @@ int orbx_stereo_match_batch_device(orbx_matcher* m,
 /* Frame generator: PCG32 seeded 0x5EED0000 + frame_index; W*H/200 random rectangles (side 6..48,
  * intensity 16..240) painted in order over mid-grey, then uniform noise in [-6,6]. */
 void orbx_synth_frame(uint32_t frame_index, int w, int h, uint8_t* out, ptrdiff_t stride);
+/* Frame::ComputeStereoMatches, sub-pixel part (src/Frame.cc:551-639), on the pyramids that `left` and `right` hold
+ * for frames 0..n_pairs-1 of their last batches (the pair's two images, extracted with identical settings): for every
+ * left keypoint whose Hamming match is below (TH_HIGH+TH_LOW)/2 the 11x11 SAD search over +-5 columns at the
+ * keypoint's level, the parabola fit and the disparity test (min_d <= d < max_d, depth = bf / d), then the median
+ * filter of the SAD distances (1.5 * 1.4 * median).  d_uright / d_depth are mvuRight / mvDepth (-1 where there is
+ * no match); d_sad is scratch of the same shape (the winning SAD per keypoint).  Device pointers, asynchronous. */
+int orbx_stereo_refine_batch_device(orbx_extractor* left, orbx_extractor* right,
+                                    const orbx_keypoint* d_kl, const int32_t* d_nl, const orbx_keypoint* d_kr,
+                                    int cap_per_frame, int n_pairs,
+                                    const int32_t* d_best_dist, const int32_t* d_best_idx,
+                                    float bf, float min_d, float max_d,
+                                    float* d_uright, float* d_depth, int32_t* d_sad, void* stream);
+/* The same for one pair with host arrays (frame 0 of each extractor's last batch); synchronous. */
+int orbx_stereo_refine(orbx_extractor* left, orbx_extractor* right,
+                       const orbx_keypoint* kl, int nl, const orbx_keypoint* kr, int nr,
+                       const int32_t* best_dist, const int32_t* best_idx, float bf, float min_d, float max_d,
+                       float* uright, float* depth);
+
 /* Stereo pair: the right image paints every rectangle shifted left by its own disparity 0..40. */
 void orbx_synth_stereo(uint32_t frame_index, int w, int h, uint8_t* left, uint8_t* right, ptrdiff_t stride);
 /* n iid uniform 256-bit descriptors from PCG32(seed). */

@@ -122,6 +122,15 @@ void  orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
                        const float* scale_factors, int nlevels, int n_rows,
                        float min_d, float max_d, int32_t* best_dist, int32_t* best_idx);
 
+/* Frame::ComputeStereoMatches sub-pixel part, src/Frame.cc:551-639, on the pyramids the two extractors built for the
+ * pair: for every left keypoint with best_dist < (TH_HIGH+TH_LOW)/2 the 11x11 SAD search over +-5 columns at the
+ * keypoint's level, parabola fit, disparity test; then the median filter over the accepted SAD distances.
+ * uright/depth get -1 where there is no match; sad gets the winning SAD (-1 where none, kept for filtered ones). */
+void  orc_stereo_refine(const orc_extractor* left, const orc_extractor* right,
+                        const orc_keypoint* kl, int nl, const orc_keypoint* kr,
+                        const int32_t* best_dist, const int32_t* best_idx,
+                        float bf, float min_d, float max_d, float* uright, float* depth, int32_t* sad);
+
 #ifdef __cplusplus
 }
 #endif

@@ -838,3 +838,85 @@ int orc_level_keypoints(const orc_extractor* ex, int level, orc_keypoint* kps, i
     for (int i = 0; i < m; ++i) kps[i] = L->kps[i];
     return L->nkp;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Frame::ComputeStereoMatches, sub-pixel part, src/Frame.cc:551-639           */
+/* ------------------------------------------------------------------------- */
+typedef struct { int dist; int idx; } dist_idx;
+static int dist_idx_cmp(const void* a, const void* b)
+{
+    const dist_idx* x = (const dist_idx*)a; const dist_idx* y = (const dist_idx*)b;
+    if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);     /* sort(vector<pair<int,int>>), :626 */
+}
+
+void orc_stereo_refine(const orc_extractor* left, const orc_extractor* right,
+                       const orc_keypoint* kl, int nl, const orc_keypoint* kr,
+                       const int32_t* best_dist, const int32_t* best_idx,
+                       float bf, float min_d, float max_d, float* uright, float* depth, int32_t* sad)
+{
+    const int thOrbDist = (100 + 50) / 2;                /* (TH_HIGH+TH_LOW)/2, :471 */
+    dist_idx* v = (dist_idx*)malloc(sizeof(dist_idx) * (size_t)(nl > 0 ? nl : 1));
+    int nv = 0;
+    for (int iL = 0; iL < nl; ++iL) {
+        uright[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1;
+        if (best_dist[iL] < 0 || best_dist[iL] >= thOrbDist) continue;           /* :552 */
+        const int oct = kl[iL].octave;
+        const float uL = kl[iL].x;
+        const float uR0 = kr[best_idx[iL]].x;
+        const float scaleFactor = left->mvInvScaleFactor[oct];
+        const float scaleduL = roundf(kl[iL].x * scaleFactor);
+        const float scaledvL = roundf(kl[iL].y * scaleFactor);
+        const float scaleduR0 = roundf(uR0 * scaleFactor);
+        const int w = 5, L = 5;
+        const level_data* ll = &left->lv[oct];
+        const level_data* lr = &right->lv[oct];
+        const ptrdiff_t psl = ll->w + 2 * EDGE_THRESHOLD, psr = lr->w + 2 * EDGE_THRESHOLD;
+        const uint8_t* imL = ll->padded + EDGE_THRESHOLD * psl + EDGE_THRESHOLD;   /* mvImagePyramid[oct] = the ROI */
+        const uint8_t* imR = lr->padded + EDGE_THRESHOLD * psr + EDGE_THRESHOLD;
+        const float iniu = scaleduR0 + L - w;
+        const float endu = scaleduR0 + L + w + 1;
+        if (iniu < 0 || endu >= lr->w) continue;                                  /* :575 */
+        const int yl = (int)scaledvL, xl = (int)scaleduL, xr = (int)scaleduR0;
+        /* rowRange/colRange outside the level throw in OpenCV (does not happen on extractor output): no match */
+        if (yl - w < 0 || yl + w >= ll->h || xl - w < 0 || xl + w >= ll->w || xr - L - w < 0) continue;
+        int bestDist = 2147483647, bestincR = 0;
+        float vDists[11];
+        const float cL = (float)imL[(ptrdiff_t)yl * psl + xl];
+        for (int incR = -L; incR <= L; ++incR) {
+            const float cR = (float)imR[(ptrdiff_t)yl * psr + xr + incR];
+            float dist = 0;                                                       /* cv::norm(IL, IR, NORM_L1): integer-valued, exact */
+            for (int dy = -w; dy <= w; ++dy)
+                for (int dx = -w; dx <= w; ++dx) {
+                    const float a = (float)imL[(ptrdiff_t)(yl + dy) * psl + xl + dx] - cL;
+                    const float b = (float)imR[(ptrdiff_t)(yl + dy) * psr + xr + incR + dx] - cR;
+                    dist += fabsf(a - b);
+                }
+            if (dist < (float)bestDist) { bestDist = (int)dist; bestincR = incR; }
+            vDists[L + incR] = dist;
+        }
+        if (bestincR == -L || bestincR == L) continue;                            /* :594 */
+        const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+        const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+        if (deltaR < -1 || deltaR > 1) continue;
+        float bestuR = left->mvScaleFactor[oct] * ((float)scaleduR0 + (float)bestincR + deltaR);
+        float disparity = uL - bestuR;
+        if (disparity >= min_d && disparity < max_d) {
+            if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }
+            depth[iL] = bf / disparity;
+            uright[iL] = bestuR;
+            sad[iL] = bestDist;
+            v[nv].dist = bestDist; v[nv].idx = iL; ++nv;
+        }
+    }
+    if (nv > 0) {                                                                 /* :626-639; empty vector: nothing to filter */
+        qsort(v, (size_t)nv, sizeof(dist_idx), dist_idx_cmp);
+        const float median = (float)v[nv / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nv - 1; i >= 0; --i) {
+            if ((float)v[i].dist < thDist) break;
+            uright[v[i].idx] = -1.0f; depth[v[i].idx] = -1.0f;
+        }
+    }
+    free(v);
+}

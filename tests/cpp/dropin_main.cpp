@@ -40,6 +40,19 @@ int main(int argc, char** argv)
     const int nm = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
     const int dist = ORB_SLAM2::ORBmatcher::DescriptorDistance(d1.row(0), d2.row(0));
 
+    // stereo, as Frame::Frame(imLeft, imRight, ...) does it (src/Frame.cc:78-81, 466-639): two extractors, then matching
+    const int sw = 752, sh = 480;
+    cv::Mat imL(sh, sw, CV_8UC1), imR(sh, sw, CV_8UC1);
+    orbx_synth_stereo(31, sw, sh, imL.ptr(), imR.ptr(), (ptrdiff_t)imL.step);
+    ORB_SLAM2::ORBextractor left(1200, 1.2f, 8, 20, 7), right(1200, 1.2f, 8, 20, 7);     // Examples/Stereo/EuRoC.yaml
+    std::vector<cv::KeyPoint> kL, kR;
+    cv::Mat dL, dR;
+    left(imL, cv::Mat(), kL, dL);
+    right(imR, cv::Mat(), kR, dR);
+    const float bf = 47.90639384423901f, fx = 435.2046959714599f;
+    std::vector<float> uRight, depth;
+    matcher.ComputeStereoMatches(left, right, kL, dL, kR, dR, bf, bf / fx, uRight, depth);
+
     FILE* f = fopen(argv[1], "wb");
     if (!f) return 4;
     int hdr[8] = {(int)k1.size(), (int)k2.size(), nm, dist, pyr3.cols, pyr3.rows, pyr3_step, ini->GetLevels()};
@@ -52,6 +65,10 @@ int main(int argc, char** argv)
     dump(f, pyr3.ptr(), (size_t)pyr3.rows * pyr3.cols);
     std::vector<float> sf = ini->GetScaleFactors();
     dump(f, sf.data(), sf.size() * sizeof(float));
+    int shdr[2] = {(int)kL.size(), (int)kR.size()};
+    dump(f, shdr, sizeof(shdr));
+    dump(f, uRight.data(), uRight.size() * sizeof(float));
+    dump(f, depth.data(), depth.size() * sizeof(float));
     fclose(f);
     printf("dropin ok: %zu / %zu keypoints, %d initial matches\n", k1.size(), k2.size(), nm);
     return 0;

@@ -59,6 +59,8 @@ lib.orc_search_by_projection_mappoints.restype = _i
 lib.orc_search_by_projection_mappoints.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp]
 lib.orc_search_by_projection_lastframe.restype = _i
 lib.orc_search_by_projection_lastframe.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp]
+lib.orc_stereo_refine.restype = None
+lib.orc_stereo_refine.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp]
 lib.orc_stereo_match.restype = None
 lib.orc_stereo_match.argtypes = [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _f, _f, _vp, _vp]
 
@@ -267,6 +269,15 @@ def search_by_projection_lastframe(qu, qv, qradius, qur, qoctave, qangle, qdesc,
                                                _ptr(k2), _ptr(d2), _ptr(uright2), len(k2), bounds[0], bounds[1], bounds[2], bounds[3],
                                                mode, th_dist, int(check_ori), _ptr(claimed))
     return claimed, n
+
+
+def stereo_refine(left, right, kl, kr, best_dist, best_idx, bf, min_d, max_d):
+    """left/right: oracle Extractors that have just extracted the pair."""
+    kl = np.ascontiguousarray(kl); kr = np.ascontiguousarray(kr)
+    bd = np.ascontiguousarray(best_dist, np.int32); bi = np.ascontiguousarray(best_idx, np.int32)
+    ur = np.zeros(len(kl), np.float32); dp = np.zeros(len(kl), np.float32); sad = np.zeros(len(kl), np.int32)
+    lib.orc_stereo_refine(left.h, right.h, _ptr(kl), len(kl), _ptr(kr), _ptr(bd), _ptr(bi), bf, min_d, max_d, _ptr(ur), _ptr(dp), _ptr(sad))
+    return ur, dp, sad
 
 
 def stereo_match(kl, dl, kr, dr, scale_factors, n_rows, min_d, max_d):

@@ -26,7 +26,10 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
     d2 = np.frombuffer(raw, np.uint8, n2 * 32, off).reshape(n2, 32); off += n2 * 32
     m12 = np.frombuffer(raw, np.int32, n1, off); off += n1 * 4
     pyr3 = np.frombuffer(raw, np.uint8, pw * ph, off).reshape(ph, pw); off += pw * ph
-    sf = np.frombuffer(raw, np.float32, nlev, off)
+    sf = np.frombuffer(raw, np.float32, nlev, off); off += nlev * 4
+    nL, nR = np.frombuffer(raw, np.int32, 2, off); off += 8
+    u_right = np.frombuffer(raw, np.float32, nL, off); off += nL * 4
+    depth = np.frombuffer(raw, np.float32, nL, off)
 
     w, h = 640, 480
     im1 = vsa.synth_frame(12, w, h)
@@ -45,3 +48,17 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
     assert nm == onm and np.array_equal(m12, om12) and nm > 100
     assert dist == oracle.descriptor_distance(od1[0], od2[0])
     assert np.array_equal(sf, oex.tables()["scale"])
+
+    # Frame::ComputeStereoMatches through ORBmatcher::ComputeStereoMatches (two extractor instances)
+    sw, sh = 752, 480
+    left, right = vsa.synth_stereo(31, sw, sh)
+    oexl, oexr = oracle.Extractor(oracle.make_params(1200)), oracle.Extractor(oracle.make_params(1200))
+    kl, dl = oexl.extract(left); kr, dr = oexr.extract(right)
+    assert nL == len(kl) and nR == len(kr)
+    bf = np.float32(47.90639384423901); fx = np.float32(435.2046959714599)
+    mb = np.float32(bf / fx)
+    max_d = float(np.float32(bf / mb))
+    o = oracle.stereo_match(kl, dl, kr, dr, oexl.tables()["scale"], sh, 0.0, max_d)
+    our, odp, _ = oracle.stereo_refine(oexl, oexr, kl, kr, o[0], o[1], float(bf), 0.0, max_d)
+    assert np.count_nonzero(our >= 0) > 50
+    assert np.array_equal(u_right, our) and np.array_equal(depth, odp)

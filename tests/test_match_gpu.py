@@ -177,13 +177,33 @@ def test_stereo_pipeline_device_resident(vsa, oracle, matcher):
                                       out["r"][0].data_ptr(), out["r"][1].data_ptr(), out["r"][2].data_ptr(),
                                       cap, B, scale, h, 0.0, bf / (bf / fx), bd.data_ptr(), bi.data_ptr(),
                                       torch.cuda.current_stream().cuda_stream)
+    # sub-pixel refinement and median filter on the two contexts' device pyramids (src/Frame.cc:551-639)
+    ur = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    dp = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    sad = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    mb = bf / fx
+    exl.stereo_refine_batch_device(exr, out["l"][0].data_ptr(), out["l"][2].data_ptr(), out["r"][0].data_ptr(), cap, B,
+                                   bd.data_ptr(), bi.data_ptr(), bf, 0.0, bf / mb, ur.data_ptr(), dp.data_ptr(), sad.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    oex = oracle.Extractor(oracle.make_params())
+    oexl, oexr = oracle.Extractor(oracle.make_params()), oracle.Extractor(oracle.make_params())
     for i in range(B):
-        kl, dl = oex.extract(pairs[i][0]); kr, dr = oex.extract(pairs[i][1])
+        kl, dl = oexl.extract(pairs[i][0]); kr, dr = oexr.extract(pairs[i][1])
         nl = int(out["l"][2][i])
         assert nl == len(kl) and int(out["r"][2][i]) == len(kr)
         assert np.array_equal(out["l"][1][i, :nl].cpu().numpy(), dl)
-        o = oracle.stereo_match(kl, dl, kr, dr, scale, h, 0.0, bf / (bf / fx))
+        o = oracle.stereo_match(kl, dl, kr, dr, scale, h, 0.0, bf / mb)
         assert np.array_equal(bd[i, :nl].cpu().numpy(), o[0]) and np.array_equal(bi[i, :nl].cpu().numpy(), o[1])
+        our, odp, osad = oracle.stereo_refine(oexl, oexr, kl, kr, o[0], o[1], bf, 0.0, bf / mb)
+        gur, gdp = ur[i, :nl].cpu().numpy(), dp[i, :nl].cpu().numpy()
+        assert np.count_nonzero(our >= 0) > 50, "the synthetic pair should give stereo matches"
+        assert np.array_equal(gur, our) and np.array_equal(gdp, odp)          # float results bit-exact
+        assert np.array_equal(sad[i, :nl].cpu().numpy(), osad)
+    # host-array form on the last pair (frame index 0 of each context must hold the pair: re-extract it alone)
+    kl_g, dl_g = exl.extract(pairs[0][0]); kr_g, dr_g = exr.extract(pairs[0][1])
+    kl, dl = oexl.extract(pairs[0][0]); kr, dr = oexr.extract(pairs[0][1])
+    o = oracle.stereo_match(kl, dl, kr, dr, scale, h, 0.0, bf / mb)
+    our, odp, _ = oracle.stereo_refine(oexl, oexr, kl, kr, o[0], o[1], bf, 0.0, bf / mb)
+    gur, gdp = exl.stereo_refine(exr, kl_g, kr_g, o[0], o[1], bf, 0.0, bf / mb)
+    assert np.array_equal(gur, our) and np.array_equal(gdp, odp)
     exl.close(); exr.close()

@@ -63,6 +63,8 @@ _SIGS = {
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _pd]),
     "orbx_pyramid_level_device": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd)]),
     "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _pd]),
+    "orbx_stereo_refine_batch_device": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "orbx_stereo_refine": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp]),
     "orbx_debug_candidates": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "orbx_debug_level_keypoints": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "orbx_distribute_octree": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, C.POINTER(_i)]),
@@ -245,6 +247,17 @@ class Extractor:
         out = np.zeros((h + 38, w + 38), np.uint8)
         _check(lib.orbx_pyramid_level(self.h, frame, level, _ptr(out), out.strides[0]))
         return out
+
+    def stereo_refine(self, right, kl, kr, best_dist, best_idx, bf, min_d, max_d):
+        """Sub-pixel part of Frame::ComputeStereoMatches on this (left) and `right` extractor's last frame 0."""
+        kl = np.ascontiguousarray(kl); kr = np.ascontiguousarray(kr)
+        bd = np.ascontiguousarray(best_dist, np.int32); bi = np.ascontiguousarray(best_idx, np.int32)
+        ur = np.zeros(len(kl), np.float32); dp = np.zeros(len(kl), np.float32)
+        _check(lib.orbx_stereo_refine(self.h, right.h, _ptr(kl), len(kl), _ptr(kr), len(kr), _ptr(bd), _ptr(bi), bf, min_d, max_d, _ptr(ur), _ptr(dp)))
+        return ur, dp
+
+    def stereo_refine_batch_device(self, right, d_kl, d_nl, d_kr, cap, n_pairs, d_bd, d_bi, bf, min_d, max_d, d_ur, d_dp, d_sad, stream=None):
+        _check(lib.orbx_stereo_refine_batch_device(self.h, right.h, d_kl, d_nl, d_kr, cap, n_pairs, d_bd, d_bi, bf, min_d, max_d, d_ur, d_dp, d_sad, stream))
 
     def debug_blurred_level(self, frame, level):
         w, h = level_size(self.params, self.width, self.height, level)

@@ -46,6 +46,7 @@ public:
     void SetDevice(int device);
     void SetBlurRounding(int mode);
     orbx_extractor* Handle() { return mpContext; }
+    int ImageHeight() const { return mnHeight; }    // mvImagePyramid[0].rows of the last operator() call
 
 protected:
     void EnsureContext(int width, int height);

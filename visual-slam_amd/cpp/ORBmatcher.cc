@@ -129,4 +129,21 @@ void ORBmatcher::StereoRowSearch(const std::vector<cv::KeyPoint>& vKeysLeft, con
           "StereoRowSearch");
 }
 
+void ORBmatcher::ComputeStereoMatches(ORBextractor& extractorLeft, ORBextractor& extractorRight,
+                                      const std::vector<cv::KeyPoint>& vKeysLeft, const cv::Mat& descLeft,
+                                      const std::vector<cv::KeyPoint>& vKeysRight, const cv::Mat& descRight,
+                                      float bf, float b, std::vector<float>& vuRight, std::vector<float>& vDepth)
+{
+    const int nl = (int)vKeysLeft.size(), nr = (int)vKeysRight.size();
+    vuRight.assign(nl, -1.0f); vDepth.assign(nl, -1.0f);                       // src/Frame.cc:468-469
+    if (nl == 0) return;
+    const float minD = 0, maxD = bf / b;                                       // :496-498
+    std::vector<int> vBestDist, vBestIdxR;
+    StereoRowSearch(vKeysLeft, descLeft, vKeysRight, descRight, extractorLeft.GetScaleFactors(), extractorLeft.ImageHeight(),
+                    minD, maxD, vBestDist, vBestIdxR);
+    check(orbx_stereo_refine(extractorLeft.Handle(), extractorRight.Handle(), as_orbx(vKeysLeft), nl, as_orbx(vKeysRight), nr,
+                             vBestDist.data(), vBestIdxR.data(), bf, minD, maxD, vuRight.data(), vDepth.data()),
+          "ComputeStereoMatches");
+}
+
 } // namespace ORB_SLAM2

@@ -8,6 +8,7 @@
 
 #include <vector>
 #include "cv_compat.h"
+#include "ORBextractor.h"
 #include "../../include/orbx.h"
 
 namespace ORB_SLAM2
@@ -61,6 +62,14 @@ public:
                          const std::vector<cv::KeyPoint>& vKeysRight, const cv::Mat& descRight,
                          const std::vector<float>& vScaleFactors, int nRows, float minD, float maxD,
                          std::vector<int>& vBestDist, std::vector<int>& vBestIdxR);
+
+    // Frame::ComputeStereoMatches whole (src/Frame.cc:466-639): the row search above, then the 11x11 SAD refinement on
+    // the pyramids the two extractors hold from their last operator() call, parabola fit, disparity test and median
+    // filter.  bf and b are Frame::mbf and Frame::mb; vuRight / vDepth are mvuRight / mvDepth.
+    void ComputeStereoMatches(ORBextractor& extractorLeft, ORBextractor& extractorRight,
+                              const std::vector<cv::KeyPoint>& vKeysLeft, const cv::Mat& descLeft,
+                              const std::vector<cv::KeyPoint>& vKeysRight, const cv::Mat& descRight,
+                              float bf, float b, std::vector<float>& vuRight, std::vector<float>& vDepth);
 
     static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
 

@@ -50,7 +50,7 @@ struct DevLevel {
     int cpr;          // 16-byte chunks per ROI row, ceil(w/16)
     unsigned cpr_magic; // ceil(2^32 / cpr): row of flat chunk index i is umulhi(i, cpr_magic)
     int border_threads; // threads of k_borders for this level
-    int pad;
+    float inv_scale;    // mvInvScaleFactor[level]
 };
 
 typedef unsigned short us16x2 __attribute__((ext_vector_type(2)));
@@ -972,6 +972,120 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     process(3, fb);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches, sub-pixel part (src/Frame.cc:551-623): one wavefront per left keypoint whose Hamming
+// match is below (TH_HIGH + TH_LOW) / 2.  11x11 windows of the two extractors' pyramids at the keypoint's level,
+// SAD (L1 norm of the centre-subtracted windows: integer-valued, so exact in integers) for the 11 column shifts,
+// parabola fit and disparity test in float exactly as written in the reference.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stereo_refine(const uint8_t* __restrict__ pyrL, const uint8_t* __restrict__ pyrR,
+                                                       unsigned long long pyr_bytes, const DevLevel* __restrict__ lv, int nlevels,
+                                                       const orbx_keypoint* __restrict__ kl, const int32_t* __restrict__ nl_arr,
+                                                       const orbx_keypoint* __restrict__ kr, int cap,
+                                                       const int32_t* __restrict__ best_dist, const int32_t* __restrict__ best_idx,
+                                                       float bf, float min_d, float max_d,
+                                                       float* __restrict__ uright, float* __restrict__ depth, int32_t* __restrict__ sad)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.y;
+    const int iL = blockIdx.x * 4 + wave;
+    if (iL >= min(nl_arr[pair], cap)) return;
+    const size_t row = (size_t)pair * cap + iL;
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_s = -1;
+    const int bd = best_dist[row];
+    constexpr int thOrbDist = (100 + 50) / 2;
+    const orbx_keypoint k = kl[row];
+    if (bd >= 0 && bd < thOrbDist && k.octave >= 0 && k.octave < nlevels) {
+        const DevLevel& L = lv[k.octave];
+        const float uR0 = kr[(size_t)pair * cap + best_idx[row]].x;
+        const float sf = L.inv_scale;
+        const float scaleduL = roundf(__fmul_rn(k.x, sf)), scaledvL = roundf(__fmul_rn(k.y, sf)), scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        constexpr int w = 5, R = 5;
+        const float iniu = scaleduR0 + (float)(R - w), endu = scaleduR0 + (float)(R + w + 1);
+        const int yl = (int)scaledvL, xl = (int)scaleduL, xr = (int)scaleduR0;
+        // rowRange/colRange outside the level throw in OpenCV (keypoints lie at least 19 pixels inside their level, so
+        // this does not happen on extractor output); such a keypoint gets no match here
+        const bool inside = yl - w >= 0 && yl + w < L.h && xl - w >= 0 && xl + w < L.w && xr - R - w >= 0;
+        if (!(iniu < 0.f || endu >= (float)L.w) && inside) {
+            const uint8_t* imL = pyrL + (unsigned long long)pair * pyr_bytes + L.roi;
+            const uint8_t* imR = pyrR + (unsigned long long)pair * pyr_bytes + L.roi;
+            const int cL = imL[(long long)yl * L.stride + xl];
+            int cR[2 * R + 1], acc[2 * R + 1];
+#pragma unroll
+            for (int i = 0; i <= 2 * R; ++i) { cR[i] = imR[(long long)yl * L.stride + xr + i - R]; acc[i] = 0; }
+            for (int pos = lane; pos < (2 * w + 1) * (2 * w + 1); pos += 64) {
+                const int dy = pos / (2 * w + 1) - w, dx = pos - (dy + w) * (2 * w + 1) - w;
+                const int a = (int)imL[(long long)(yl + dy) * L.stride + xl + dx] - cL;
+                const uint8_t* rr = imR + (long long)(yl + dy) * L.stride + xr + dx - R;
+#pragma unroll
+                for (int i = 0; i <= 2 * R; ++i) { const int b = (int)rr[i] - cR[i]; acc[i] += abs(a - b); }
+            }
+#pragma unroll
+            for (int i = 0; i <= 2 * R; ++i)
+                for (int d = 32; d >= 1; d >>= 1) acc[i] += __shfl_xor(acc[i], d, 64);
+            int bestDist = 2147483647, bestinc = 0;
+#pragma unroll
+            for (int i = 0; i <= 2 * R; ++i) if (acc[i] < bestDist) { bestDist = acc[i]; bestinc = i - R; }
+            if (bestinc != -R && bestinc != R) {
+                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int i = 1; i < 2 * R; ++i) if (i - R == bestinc) { d1 = (float)acc[i - 1]; d2 = (float)acc[i]; d3 = (float)acc[i + 1]; }
+                const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+                if (!(deltaR < -1.f || deltaR > 1.f)) {
+                    float bestuR = __fmul_rn(L.scale, __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+                    float disparity = __fsub_rn(k.x, bestuR);
+                    if (disparity >= min_d && disparity < max_d) {
+                        if (disparity <= 0.f) { disparity = 0.01f; bestuR = (float)((double)k.x - 0.01); }
+                        out_d = __fdiv_rn(bf, disparity);
+                        out_u = bestuR;
+                        out_s = bestDist;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { uright[row] = out_u; depth[row] = out_d; sad[row] = out_s; }
+}
+
+// Median filter of the accepted SAD distances (src/Frame.cc:626-639): one workgroup per pair.  The reference sorts
+// (distance, left index) pairs and takes element size/2; the rank of a pair is the number of smaller packed keys.
+__global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict__ nl_arr, int cap, const int32_t* __restrict__ sad,
+                                                       float* __restrict__ uright, float* __restrict__ depth)
+{
+    extern __shared__ uint32_t s_key[];
+    __shared__ int s_nv, s_median;
+    const int pair = blockIdx.x;
+    const int nl = min(nl_arr[pair], cap);
+    const size_t base = (size_t)pair * cap;
+    if (threadIdx.x == 0) { s_nv = 0; s_median = -1; }
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < nl; i += 256) {
+        const int s = sad[base + i];
+        s_key[i] = s >= 0 ? ((uint32_t)s << 16) | (uint32_t)i : 0xFFFFFFFFu;
+        mine += s >= 0;
+    }
+    if (mine) atomicAdd(&s_nv, mine);
+    __syncthreads();
+    const int nv = s_nv;
+    if (nv == 0) return;
+    for (int i = threadIdx.x; i < nl; i += 256) {
+        const uint32_t key = s_key[i];
+        if (key == 0xFFFFFFFFu) continue;
+        int rank = 0;
+        for (int j = 0; j < nl; ++j) rank += s_key[j] < key;
+        if (rank == nv / 2) s_median = (int)(key >> 16);
+    }
+    __syncthreads();
+    const float thDist = 1.5f * 1.4f * (float)s_median;
+    for (int i = threadIdx.x; i < nl; i += 256) {
+        const uint32_t key = s_key[i];
+        if (key != 0xFFFFFFFFu && !((float)(key >> 16) < thDist)) { uright[base + i] = -1.0f; depth[base + i] = -1.0f; }
+    }
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1051,7 +1165,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         d.maxBorderX = g.maxBorderX; d.maxBorderY = g.maxBorderY;
         d.cell_first = g.cell_first; d.cell_count = g.cell_count; d.cand_offset = g.cand_offset; d.cand_cap = g.cand_cap;
         d.quota = g.quota; d.nIni = g.nIni; d.hX = g.hX; d.kp_offset = g.kp_offset; d.kp_cap = g.kp_cap;
-        d.area2x = g.area2x; d.rx_offset = g.rx_offset; d.ry_offset = g.ry_offset; d.scale = g.scale; d.kp_size = g.kp_size;
+        d.area2x = g.area2x; d.rx_offset = g.rx_offset; d.ry_offset = g.ry_offset; d.scale = g.scale; d.inv_scale = geo.tables.inv_scale[l]; d.kp_size = g.kp_size;
         d.key_offset = key_off;
         d.fast_resize = g.fast_resize;
         if (l > 0 && !g.fast_resize) ++ex->generic_levels;
@@ -1293,6 +1407,71 @@ int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, p
     const uint8_t* src = ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes + L.offset + (kRoiX - kEdge);
     HIP_CHECK(hipMemcpy2D(dst, dst_stride, src, L.stride, L.w + 2 * kEdge, L.rows, hipMemcpyDeviceToHost));
     return ORBX_OK;
+}
+
+int orbx_stereo_refine_batch_device(orbx_extractor* left, orbx_extractor* right,
+                                    const orbx_keypoint* d_kl, const int32_t* d_nl, const orbx_keypoint* d_kr, int cap_per_frame,
+                                    int n_pairs, const int32_t* d_best_dist, const int32_t* d_best_idx, float bf, float min_d,
+                                    float max_d, float* d_uright, float* d_depth, int32_t* d_sad, void* stream)
+{
+    if (!left || !right || !d_kl || !d_nl || !d_kr || !d_best_dist || !d_best_idx || !d_uright || !d_depth || !d_sad) {
+        set_error("orbx_stereo_refine_batch_device: null pointer"); return ORBX_ERR_BAD_ARG;
+    }
+    if (left->device != right->device || left->geo.width != right->geo.width || left->geo.height != right->geo.height ||
+        left->geo.nlevels != right->geo.nlevels || left->params.scale_factor != right->params.scale_factor) {
+        set_error("orbx_stereo_refine_batch_device: the two extractors must share device, image size and pyramid"); return ORBX_ERR_BAD_ARG;
+    }
+    if (n_pairs < 1 || n_pairs > left->max_batch || n_pairs > right->max_batch || cap_per_frame < 1 || cap_per_frame > 16000) {
+        set_error("orbx_stereo_refine_batch_device: n_pairs outside the contexts' batch or cap_per_frame outside [1, 16000]"); return ORBX_ERR_BAD_ARG;
+    }
+    HIP_CHECK(hipSetDevice(left->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_stereo_refine, dim3((cap_per_frame + 3) / 4, n_pairs), dim3(256), 0, st, left->d_pyr, right->d_pyr,
+                       (unsigned long long)left->geo.pyr_bytes, left->d_lv, left->geo.nlevels, d_kl, d_nl, d_kr, cap_per_frame,
+                       d_best_dist, d_best_idx, bf, min_d, max_d, d_uright, d_depth, d_sad);
+    hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(256), sizeof(uint32_t) * (size_t)cap_per_frame, st, d_nl, cap_per_frame,
+                       d_sad, d_uright, d_depth);
+    HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_stereo_refine(orbx_extractor* left, orbx_extractor* right, const orbx_keypoint* kl, int nl, const orbx_keypoint* kr, int nr,
+                       const int32_t* best_dist, const int32_t* best_idx, float bf, float min_d, float max_d,
+                       float* uright, float* depth)
+{
+    if (!left || !right || nl < 0 || nr < 0) { set_error("orbx_stereo_refine: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (nl == 0) return ORBX_OK;
+    if (!kl || !best_dist || !best_idx || !uright || !depth || (nr > 0 && !kr)) { set_error("orbx_stereo_refine: null pointer"); return ORBX_ERR_BAD_ARG; }
+    for (int i = 0; i < nl; ++i)
+        if (best_dist[i] >= 0 && (best_idx[i] < 0 || best_idx[i] >= nr)) { set_error("orbx_stereo_refine: best_idx out of range"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(left->device));
+    const int cap = std::max(nl, std::max(nr, 1));
+    orbx_keypoint *d_kl = nullptr, *d_kr = nullptr; int32_t *d_i = nullptr; float* d_f = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_kl); (void)hipFree(d_kr); (void)hipFree(d_i); (void)hipFree(d_f); };
+    int rc = ORBX_OK;
+    do {
+        if (hipMalloc(&d_kl, sizeof(orbx_keypoint) * cap) != hipSuccess || hipMalloc(&d_kr, sizeof(orbx_keypoint) * cap) != hipSuccess ||
+            hipMalloc(&d_i, sizeof(int32_t) * (3 * (size_t)cap + 1)) != hipSuccess || hipMalloc(&d_f, sizeof(float) * 2 * (size_t)cap) != hipSuccess) {
+            set_error("orbx_stereo_refine: hipMalloc failed"); rc = ORBX_ERR_HIP; break;
+        }
+        hipStream_t st = left->stream;
+        (void)hipStreamSynchronize(right->stream);
+        bool ok = hipMemcpyAsync(d_kl, kl, sizeof(orbx_keypoint) * nl, hipMemcpyHostToDevice, st) == hipSuccess;
+        if (nr) ok = ok && hipMemcpyAsync(d_kr, kr, sizeof(orbx_keypoint) * nr, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d_i, best_dist, sizeof(int32_t) * nl, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d_i + cap, best_idx, sizeof(int32_t) * nl, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d_i + 3 * (size_t)cap, &nl, sizeof(int32_t), hipMemcpyHostToDevice, st) == hipSuccess;
+        if (!ok) { set_error("orbx_stereo_refine: upload failed"); rc = ORBX_ERR_HIP; break; }
+        rc = orbx_stereo_refine_batch_device(left, right, d_kl, d_i + 3 * (size_t)cap, d_kr, cap, 1, d_i, d_i + cap, bf, min_d, max_d,
+                                             d_f, d_f + cap, d_i + 2 * (size_t)cap, st);
+        if (rc != ORBX_OK) break;
+        ok = hipMemcpyAsync(uright, d_f, sizeof(float) * nl, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipMemcpyAsync(depth, d_f + cap, sizeof(float) * nl, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+        if (!ok) { set_error("orbx_stereo_refine: download failed"); rc = ORBX_ERR_HIP; }
+    } while (0);
+    cleanup();
+    return rc;
 }
 
 int orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride)
