@@ -192,6 +192,42 @@ int orbx_search_by_projection_lastframe(orbx_matcher* m,
                                         float minX, float maxX, float minY, float maxY,
                                         int mode, int th_dist, int check_ori, int32_t* claimed, int* nmatches);
 
+/* A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) flattened: node ids ascending, the feature
+ * indices of node k in features[node_ptr[k] .. node_ptr[k+1]) in their list order. */
+typedef struct orbx_feature_vector {
+    const uint32_t* node_ids;
+    const int32_t* node_ptr;
+    const int32_t* features;
+    int32_t n_nodes;
+} orbx_feature_vector;
+
+/* ORBmatcher::SearchByBoW, both forms: features of side 1 are matched against the features of side 2 that share their
+ * vocabulary node, best-2 with ratio test, TH_LOW, rotation histogram.
+ *   keyframe_form 0: SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:159-291): side 1 = key frame (eligible1[i]:
+ *     feature i has a good map point), side 2 = frame (eligible2 all ones, or NULL); accepts best <= TH_LOW;
+ *     the reference's vpMapPointMatches[i2] is the map point of key-frame feature match21[i2].
+ *   keyframe_form 1: SearchByBoW(KeyFrame*, KeyFrame*, ...) (:525-658): eligible on both sides = has a good map point;
+ *     accepts best < TH_LOW; the reference's vpMatches12[i1] is the map point of feature match12[i1] of key frame 2.
+ * angle1 / angle2: keypoint angles the reference feeds the histogram with.  match12[n1], match21[n2]: -1 = none. */
+int orbx_search_by_bow(orbx_matcher* m,
+                       const uint8_t* d1, const float* angle1, const uint8_t* eligible1, int n1, const orbx_feature_vector* fv1,
+                       const uint8_t* d2, const float* angle2, const uint8_t* eligible2, int n2, const orbx_feature_vector* fv2,
+                       float nnratio, int check_ori, int keyframe_form,
+                       int32_t* match12, int32_t* match21, int* nmatches);
+
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:660-826) with CheckDistEpipolarLine (:140-157): features of key
+ * frame 1 without a map point against features of key frame 2 without one in the same vocabulary node, best-1 within
+ * TH_LOW subject to the epipole-distance and epipolar-line tests.  k1/k2 = mvKeysUn, uright = mvuRight (>= 0: stereo),
+ * F12 row-major 3x3, (ex, ey) the epipole in image 2 (:667-673), scale_factors2 / level_sigma2_2 of key frame 2.
+ * match12[n1]: index in key frame 2 or -1 (vMatchedPairs is its list form). */
+int orbx_search_for_triangulation(orbx_matcher* m,
+                                  const orbx_keypoint* k1, const uint8_t* d1, const uint8_t* has_mp1, const float* uright1, int n1,
+                                  const orbx_feature_vector* fv1,
+                                  const orbx_keypoint* k2, const uint8_t* d2, const uint8_t* has_mp2, const float* uright2, int n2,
+                                  const orbx_feature_vector* fv2,
+                                  const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                  int nlevels, int only_stereo, int check_ori, int32_t* match12, int* nmatches);
+
 /* Frame::ComputeStereoMatches, Hamming part (src/Frame.cc:466-549): per left keypoint the best right
  * keypoint in its row band (start value TH_HIGH=100, index 0); best_dist = -1 marks a left keypoint the
  * reference skips before the loop (:513-520). */

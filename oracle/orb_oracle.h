@@ -122,6 +122,25 @@ void  orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
                        const float* scale_factors, int nlevels, int n_rows,
                        float min_d, float max_d, int32_t* best_dist, int32_t* best_idx);
 
+/* DBoW2::FeatureVector flattened: node ids ascending; features of node k at features[node_ptr[k]..node_ptr[k+1]). */
+typedef struct orc_feature_vector {
+    const uint32_t* node_ids; const int32_t* node_ptr; const int32_t* features; int32_t n_nodes;
+} orc_feature_vector;
+
+/* ORBmatcher::SearchByBoW: keyframe_form 0 = (KeyFrame*, Frame&) src/ORBmatcher.cc:159-291, 1 = (KeyFrame*, KeyFrame*) :525-658.
+ * eligible = "has a good map point" (side 2 of form 0: may be NULL = all).  Returns nmatches. */
+int   orc_search_by_bow(const uint8_t* d1, const float* angle1, const uint8_t* eligible1, int n1, const orc_feature_vector* fv1,
+                        const uint8_t* d2, const float* angle2, const uint8_t* eligible2, int n2, const orc_feature_vector* fv2,
+                        float nnratio, int check_ori, int keyframe_form, int32_t* match12, int32_t* match21);
+
+/* ORBmatcher::SearchForTriangulation src/ORBmatcher.cc:660-826 with CheckDistEpipolarLine :140-157.  Returns nmatches. */
+int   orc_search_for_triangulation(const orc_keypoint* k1, const uint8_t* d1, const uint8_t* has_mp1, const float* uright1, int n1,
+                                   const orc_feature_vector* fv1,
+                                   const orc_keypoint* k2, const uint8_t* d2, const uint8_t* has_mp2, const float* uright2, int n2,
+                                   const orc_feature_vector* fv2,
+                                   const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                   int only_stereo, int check_ori, int32_t* match12);
+
 /* Frame::ComputeStereoMatches sub-pixel part, src/Frame.cc:551-639, on the pyramids the two extractors built for the
  * pair: for every left keypoint with best_dist < (TH_HIGH+TH_LOW)/2 the 11x11 SAD search over +-5 columns at the
  * keypoint's level, parabola fit, disparity test; then the median filter over the accepted SAD distances.

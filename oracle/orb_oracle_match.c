@@ -361,3 +361,137 @@ void orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
     }
     free(fill); free(items); free(row_count);
 }
+
+/* ------------------------------------------------------------------------- */
+/* Vocabulary-node matchers                                                    */
+/* ------------------------------------------------------------------------- */
+/* std::map::lower_bound on the flattened feature vector: first node index whose id is not below `id` */
+static int fv_lower_bound(const orc_feature_vector* fv, uint32_t id)
+{
+    int k = 0;
+    while (k < fv->n_nodes && fv->node_ids[k] < id) ++k;
+    return k;
+}
+
+/* ORBmatcher::SearchByBoW, src/ORBmatcher.cc:159-291 (keyframe_form 0) / :525-658 (keyframe_form 1) */
+int orc_search_by_bow(const uint8_t* d1, const float* angle1, const uint8_t* eligible1, int n1, const orc_feature_vector* fv1,
+                      const uint8_t* d2, const float* angle2, const uint8_t* eligible2, int n2, const orc_feature_vector* fv2,
+                      float nnratio, int check_ori, int keyframe_form, int32_t* match12, int32_t* match21)
+{
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    for (int i = 0; i < n2; ++i) match21[i] = -1;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; ++i) { rotHist[i] = (int*)malloc(sizeof(int) * (size_t)(n1 + 1)); rotN[i] = 0; }
+    int it1 = 0, it2 = 0;
+    while (it1 < fv1->n_nodes && it2 < fv2->n_nodes) {
+        if (fv1->node_ids[it1] == fv2->node_ids[it2]) {
+            for (int c1 = fv1->node_ptr[it1]; c1 < fv1->node_ptr[it1 + 1]; ++c1) {
+                const int idx1 = fv1->features[c1];
+                if (!eligible1[idx1]) continue;                          /* !pMP || pMP->isBad() */
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int c2 = fv2->node_ptr[it2]; c2 < fv2->node_ptr[it2 + 1]; ++c2) {
+                    const int idx2 = fv2->features[c2];
+                    if (match21[idx2] >= 0) continue;                    /* vpMapPointMatches[realIdxF] / vbMatched2[idx2] */
+                    if (eligible2 && !eligible2[idx2]) continue;
+                    const int dist = orc_descriptor_distance(d1 + (size_t)idx1 * 32, d2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (keyframe_form ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW) {
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        match12[idx1] = bestIdx2; match21[bestIdx2] = idx1;
+                        if (check_ori) { const int bin = rot_bin(angle1[idx1], angle2[bestIdx2]); rotHist[bin][rotN[bin]++] = idx1; }
+                        nmatches++;
+                    }
+                }
+            }
+            it1++; it2++;
+        } else if (fv1->node_ids[it1] < fv2->node_ids[it2]) it1 = fv_lower_bound(fv1, fv2->node_ids[it2]);
+        else it2 = fv_lower_bound(fv2, fv1->node_ids[it1]);
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_compute_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) {
+                const int idx1 = rotHist[i][j];
+                match21[match12[idx1]] = -1; match12[idx1] = -1; nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; ++i) free(rotHist[i]);
+    return nmatches;
+}
+
+/* ORBmatcher::CheckDistEpipolarLine, src/ORBmatcher.cc:140-157 */
+static int check_dist_epipolar_line(const orc_keypoint* kp1, const orc_keypoint* kp2, const float* F12, const float* sigma2_2)
+{
+    const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+    const float b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+    const float c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2_2[kp2->octave];
+}
+
+/* ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:660-826 */
+int orc_search_for_triangulation(const orc_keypoint* k1, const uint8_t* d1, const uint8_t* has_mp1, const float* uright1, int n1,
+                                 const orc_feature_vector* fv1,
+                                 const orc_keypoint* k2, const uint8_t* d2, const uint8_t* has_mp2, const float* uright2, int n2,
+                                 const orc_feature_vector* fv2,
+                                 const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                 int only_stereo, int check_ori, int32_t* match12)
+{
+    (void)n2;
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; ++i) { rotHist[i] = (int*)malloc(sizeof(int) * (size_t)(n1 + 1)); rotN[i] = 0; }
+    int it1 = 0, it2 = 0;
+    while (it1 < fv1->n_nodes && it2 < fv2->n_nodes) {
+        if (fv1->node_ids[it1] == fv2->node_ids[it2]) {
+            for (int c1 = fv1->node_ptr[it1]; c1 < fv1->node_ptr[it1 + 1]; ++c1) {
+                const int idx1 = fv1->features[c1];
+                if (has_mp1[idx1]) continue;
+                const int bStereo1 = uright1[idx1] >= 0;
+                if (only_stereo && !bStereo1) continue;
+                const orc_keypoint* kp1 = &k1[idx1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int c2 = fv2->node_ptr[it2]; c2 < fv2->node_ptr[it2 + 1]; ++c2) {
+                    const int idx2 = fv2->features[c2];
+                    if (has_mp2[idx2]) continue;                          /* vbMatched2 is never set in the reference */
+                    const int bStereo2 = uright2[idx2] >= 0;
+                    if (only_stereo && !bStereo2) continue;
+                    const int dist = orc_descriptor_distance(d1 + (size_t)idx1 * 32, d2 + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const orc_keypoint* kp2 = &k2[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - kp2->x, distey = ey - kp2->y;
+                        if (distex * distex + distey * distey < 100 * scale_factors2[kp2->octave]) continue;
+                    }
+                    if (check_dist_epipolar_line(kp1, kp2, F12, level_sigma2_2)) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[idx1] = bestIdx2; nmatches++;
+                    if (check_ori) { const int bin = rot_bin(kp1->angle, k2[bestIdx2].angle); rotHist[bin][rotN[bin]++] = idx1; }
+                }
+            }
+            it1++; it2++;
+        } else if (fv1->node_ids[it1] < fv2->node_ids[it2]) it1 = fv_lower_bound(fv1, fv2->node_ids[it2]);
+        else it2 = fv_lower_bound(fv2, fv1->node_ids[it1]);
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_compute_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) { match12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; ++i) free(rotHist[i]);
+    return nmatches;
+}

@@ -40,6 +40,16 @@ int main(int argc, char** argv)
     const int nm = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
     const int dist = ORB_SLAM2::ORBmatcher::DescriptorDistance(d1.row(0), d2.row(0));
 
+    // SearchByBoW(KeyFrame*, Frame&, ...) as Tracking::TrackReferenceKeyFrame calls it (src/Tracking.cc:764-766), with a
+    // stand-in vocabulary: the node of a feature is read off ten descriptor bits
+    ORB_SLAM2::FeatureVectorMap fvKF, fvF;
+    for (int i = 0; i < d1.rows; ++i) fvKF[((unsigned)(d1.ptr(i)[0] >> 3) << 5) | (unsigned)(d1.ptr(i)[16] >> 3)].push_back((unsigned)i);
+    for (int i = 0; i < d2.rows; ++i) fvF[((unsigned)(d2.ptr(i)[0] >> 3) << 5) | (unsigned)(d2.ptr(i)[16] >> 3)].push_back((unsigned)i);
+    std::vector<bool> goodKF(k1.size(), true);
+    std::vector<int> bowMatchesF;
+    ORB_SLAM2::ORBmatcher bowMatcher(0.7, true);
+    const int nbow = bowMatcher.SearchByBoW(F1, goodKF, fvKF, F2, k2, fvF, bowMatchesF);
+
     // stereo, as Frame::Frame(imLeft, imRight, ...) does it (src/Frame.cc:78-81, 466-639): two extractors, then matching
     const int sw = 752, sh = 480;
     cv::Mat imL(sh, sw, CV_8UC1), imR(sh, sw, CV_8UC1);
@@ -65,6 +75,8 @@ int main(int argc, char** argv)
     dump(f, pyr3.ptr(), (size_t)pyr3.rows * pyr3.cols);
     std::vector<float> sf = ini->GetScaleFactors();
     dump(f, sf.data(), sf.size() * sizeof(float));
+    dump(f, &nbow, sizeof(int));
+    dump(f, bowMatchesF.data(), bowMatchesF.size() * sizeof(int));
     int shdr[2] = {(int)kL.size(), (int)kR.size()};
     dump(f, shdr, sizeof(shdr));
     dump(f, uRight.data(), uRight.size() * sizeof(float));

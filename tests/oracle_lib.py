@@ -245,6 +245,51 @@ def search_for_initialization(k1, d1, k2, d2, bounds, prev_matched, window=100, 
     return m12, n, prev
 
 
+class FeatureVectorC(C.Structure):
+    _fields_ = [("node_ids", _vp), ("node_ptr", _vp), ("features", _vp), ("n_nodes", C.c_int32)]
+
+
+def feature_vector(node_of_feature):
+    node_of_feature = np.asarray(node_of_feature, np.int64)
+    ids = np.unique(node_of_feature).astype(np.uint32)
+    order = np.argsort(node_of_feature, kind="stable").astype(np.int32)
+    counts = np.array([np.count_nonzero(node_of_feature == i) for i in ids], np.int64)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    fv = FeatureVectorC(_ptr(ids) if len(ids) else None, _ptr(ptr), _ptr(order) if len(order) else None, len(ids))
+    return fv, (ids, ptr, order)
+
+
+def search_by_bow(d1, angle1, eligible1, nodes1, d2, angle2, eligible2, nodes2, nnratio=0.7, check_ori=True, keyframe_form=0):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    a1 = np.ascontiguousarray(angle1, np.float32); a2 = np.ascontiguousarray(angle2, np.float32)
+    e1 = np.ascontiguousarray(eligible1, np.uint8)
+    e2 = None if eligible2 is None else np.ascontiguousarray(eligible2, np.uint8)
+    fv1, keep1 = feature_vector(nodes1); fv2, keep2 = feature_vector(nodes2)
+    m12 = np.full(len(d1), -1, np.int32); m21 = np.full(len(d2), -1, np.int32)
+    lib.orc_search_by_bow.restype = C.c_int
+    lib.orc_search_by_bow.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _vp, _vp]
+    n = lib.orc_search_by_bow(_ptr(d1), _ptr(a1), _ptr(e1), len(d1), C.byref(fv1), _ptr(d2), _ptr(a2), None if e2 is None else _ptr(e2),
+                              len(d2), C.byref(fv2), nnratio, int(check_ori), keyframe_form, _ptr(m12), _ptr(m21))
+    return m12, m21, n
+
+
+def search_for_triangulation(k1, d1, has_mp1, uright1, nodes1, k2, d2, has_mp2, uright2, nodes2, F12, ex, ey, scale2, sigma2_2,
+                             only_stereo=False, check_ori=True):
+    k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+    u1 = np.ascontiguousarray(uright1, np.float32); u2 = np.ascontiguousarray(uright2, np.float32)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2_2, np.float32)
+    fv1, keep1 = feature_vector(nodes1); fv2, keep2 = feature_vector(nodes2)
+    m12 = np.full(len(k1), -1, np.int32)
+    lib.orc_search_for_triangulation.restype = C.c_int
+    lib.orc_search_for_triangulation.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _vp]
+    n = lib.orc_search_for_triangulation(_ptr(k1), _ptr(d1), _ptr(h1), _ptr(u1), len(k1), C.byref(fv1), _ptr(k2), _ptr(d2), _ptr(h2), _ptr(u2),
+                                         len(k2), C.byref(fv2), _ptr(F), ex, ey, _ptr(sc), _ptr(sg), int(only_stereo), int(check_ori), _ptr(m12))
+    return m12, n
+
+
 def search_by_projection_mappoints(qu, qv, qr, qur, qlevel, qdesc, k2, d2, uright2, bounds, nnratio, claimed):
     f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
     qu, qv, qr, qur, uright2 = f32(qu), f32(qv), f32(qr), f32(qur), f32(uright2)

@@ -27,6 +27,8 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
     m12 = np.frombuffer(raw, np.int32, n1, off); off += n1 * 4
     pyr3 = np.frombuffer(raw, np.uint8, pw * ph, off).reshape(ph, pw); off += pw * ph
     sf = np.frombuffer(raw, np.float32, nlev, off); off += nlev * 4
+    nbow = int(np.frombuffer(raw, np.int32, 1, off)[0]); off += 4
+    bow_f = np.frombuffer(raw, np.int32, n2, off); off += n2 * 4
     nL, nR = np.frombuffer(raw, np.int32, 2, off); off += 8
     u_right = np.frombuffer(raw, np.float32, nL, off); off += nL * 4
     depth = np.frombuffer(raw, np.float32, nL, off)
@@ -48,6 +50,12 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
     assert nm == onm and np.array_equal(m12, om12) and nm > 100
     assert dist == oracle.descriptor_distance(od1[0], od2[0])
     assert np.array_equal(sf, oex.tables()["scale"])
+
+    # SearchByBoW(KeyFrame*, Frame&) with the stand-in vocabulary of the driver
+    nodes = lambda d: ((d[:, 0].astype(np.int64) >> 3) << 5) | (d[:, 16].astype(np.int64) >> 3)
+    o12, o21, on = oracle.search_by_bow(od1, ok1["angle"], np.ones(len(ok1), np.uint8), nodes(od1), od2, ok2["angle"], None, nodes(od2),
+                                        0.7, True, 0)
+    assert nbow == on and np.array_equal(bow_f, o21) and nbow > 50
 
     # Frame::ComputeStereoMatches through ORBmatcher::ComputeStereoMatches (two extractor instances)
     sw, sh = 752, 480

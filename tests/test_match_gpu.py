@@ -207,3 +207,50 @@ def test_stereo_pipeline_device_resident(vsa, oracle, matcher):
     gur, gdp = exl.stereo_refine(exr, kl_g, kr_g, o[0], o[1], bf, 0.0, bf / mb)
     assert np.array_equal(gur, our) and np.array_equal(gdp, odp)
     exl.close(); exr.close()
+
+
+def _nodes(desc):
+    """A stand-in vocabulary: the node of a feature is read off ten descriptor bits, so most true correspondences share it."""
+    return ((desc[:, 0].astype(np.int64) >> 3) << 5) | (desc[:, 16].astype(np.int64) >> 3)
+
+
+@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow(vsa, oracle, matcher, motion_features, form, check_ori):
+    w, h, k1, d1, k2, d2 = motion_features
+    rng = np.random.default_rng(5 + form)
+    e1 = rng.random(len(k1)) < 0.8                       # key-frame features with a good map point
+    e2 = (rng.random(len(k2)) < 0.8) if form == 1 else None
+    n1, n2 = _nodes(d1), _nodes(d2)
+    for ratio in (0.7, 0.9):
+        g = matcher.search_by_bow(d1, k1["angle"], e1, n1, d2, k2["angle"], e2, n2, ratio, check_ori, form)
+        o = oracle.search_by_bow(d1, k1["angle"], e1, n1, d2, k2["angle"], e2, n2, ratio, check_ori, form)
+        assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+        assert g[2] > 50
+    # empty sides and disjoint vocabularies
+    g = matcher.search_by_bow(d1[:0], k1["angle"][:0], e1[:0], n1[:0], d2, k2["angle"], e2, n2, 0.7, check_ori, form)
+    assert g[2] == 0 and np.all(g[1] == -1)
+    g = matcher.search_by_bow(d1, k1["angle"], e1, n1, d2, k2["angle"], e2, n2 + 100000, 0.7, check_ori, form)
+    assert g[2] == 0
+
+
+@pytest.mark.parametrize("only_stereo", [False, True])
+def test_search_for_triangulation(vsa, oracle, matcher, motion_features, only_stereo):
+    w, h, k1, d1, k2, d2 = motion_features
+    rng = np.random.default_rng(9)
+    has1 = rng.random(len(k1)) < 0.5
+    has2 = rng.random(len(k2)) < 0.5
+    ur1 = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 10.0, -1.0).astype(np.float32)
+    ur2 = np.where(rng.random(len(k2)) < 0.5, k2["x"] - 10.0, -1.0).astype(np.float32)
+    # fundamental matrix of a pure image translation (x2 = x1 + t): epipolar lines parallel to t; a scale keeps values generic
+    t = np.array([5.0, 3.0, 0.0])
+    F12 = (1e-3 * np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])).T.astype(np.float32)
+    tabs = vsa.scale_tables(vsa.make_params(2000))
+    n1, n2 = _nodes(d1), _nodes(d2)
+    for check_ori in (True, False):
+        g = matcher.search_for_triangulation(k1, d1, has1, ur1, n1, k2, d2, has2, ur2, n2, F12, 320.0, 240.0, tabs["scale"], tabs["sigma2"],
+                                             only_stereo, check_ori)
+        o = oracle.search_for_triangulation(k1, d1, has1, ur1, n1, k2, d2, has2, ur2, n2, F12, 320.0, 240.0, tabs["scale"], tabs["sigma2"],
+                                            only_stereo, check_ori)
+        assert g[1] == o[1] and np.array_equal(g[0], o[0])
+        assert g[1] > 10

@@ -63,6 +63,9 @@ _SIGS = {
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _pd]),
     "orbx_pyramid_level_device": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd)]),
     "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _pd]),
+    "orbx_search_by_bow": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _vp, _vp, C.POINTER(_i)]),
+    "orbx_search_for_triangulation": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp,
+                                           _i, _i, _i, _vp, C.POINTER(_i)]),
     "orbx_stereo_refine_batch_device": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "orbx_stereo_refine": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp]),
     "orbx_debug_candidates": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
@@ -287,6 +290,23 @@ class Extractor:
         return ms
 
 
+class FeatureVectorC(C.Structure):
+    """orbx_feature_vector: a DBoW2::FeatureVector flattened (node ids ascending, CSR feature lists)."""
+    _fields_ = [("node_ids", _vp), ("node_ptr", _vp), ("features", _vp), ("n_nodes", C.c_int32)]
+
+
+def feature_vector(node_of_feature):
+    """Builds the flattened feature vector of features 0..n-1 from the vocabulary node of each (features of a node in
+    index order, as DBoW2 appends them).  Returns (struct, keepalive arrays)."""
+    node_of_feature = np.asarray(node_of_feature, np.int64)
+    ids = np.unique(node_of_feature).astype(np.uint32)
+    order = np.argsort(node_of_feature, kind="stable").astype(np.int32)
+    counts = np.array([np.count_nonzero(node_of_feature == i) for i in ids], np.int64)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    fv = FeatureVectorC(_ptr(ids) if len(ids) else None, _ptr(ptr), _ptr(order) if len(order) else None, len(ids))
+    return fv, (ids, ptr, order)
+
+
 class Matcher:
     """orbx_matcher context."""
 
@@ -334,6 +354,35 @@ class Matcher:
                                                   bounds[0], bounds[1], bounds[2], bounds[3], _ptr(prev), window, nnratio,
                                                   int(check_ori), _ptr(m12), C.byref(n)))
         return m12, n.value, prev
+
+    def search_by_bow(self, d1, angle1, eligible1, nodes1, d2, angle2, eligible2, nodes2, nnratio=0.7, check_ori=True, keyframe_form=0):
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        a1 = np.ascontiguousarray(angle1, np.float32); a2 = np.ascontiguousarray(angle2, np.float32)
+        e1 = np.ascontiguousarray(eligible1, np.uint8)
+        e2 = None if eligible2 is None else np.ascontiguousarray(eligible2, np.uint8)
+        fv1, keep1 = feature_vector(nodes1); fv2, keep2 = feature_vector(nodes2)
+        m12 = np.full(len(d1), -1, np.int32); m21 = np.full(len(d2), -1, np.int32)
+        n = C.c_int()
+        _check(lib.orbx_search_by_bow(self.h, _ptr(d1), _ptr(a1), _ptr(e1), len(d1), C.byref(fv1), _ptr(d2), _ptr(a2),
+                                      None if e2 is None else _ptr(e2), len(d2), C.byref(fv2), nnratio, int(check_ori), keyframe_form,
+                                      _ptr(m12), _ptr(m21), C.byref(n)))
+        return m12, m21, n.value
+
+    def search_for_triangulation(self, k1, d1, has_mp1, uright1, nodes1, k2, d2, has_mp2, uright2, nodes2, F12, ex, ey,
+                                 scale2, sigma2_2, only_stereo=False, check_ori=True):
+        k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        u1 = np.ascontiguousarray(uright1, np.float32); u2 = np.ascontiguousarray(uright2, np.float32)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2_2, np.float32)
+        fv1, keep1 = feature_vector(nodes1); fv2, keep2 = feature_vector(nodes2)
+        m12 = np.full(len(k1), -1, np.int32)
+        n = C.c_int()
+        _check(lib.orbx_search_for_triangulation(self.h, _ptr(k1), _ptr(d1), _ptr(h1), _ptr(u1), len(k1), C.byref(fv1),
+                                                 _ptr(k2), _ptr(d2), _ptr(h2), _ptr(u2), len(k2), C.byref(fv2), _ptr(F), ex, ey,
+                                                 _ptr(sc), _ptr(sg), len(sc), int(only_stereo), int(check_ori), _ptr(m12), C.byref(n)))
+        return m12, n.value
 
     def search_by_projection_mappoints(self, qu, qv, qr, qur, qlevel, qdesc, k2, d2, uright2, bounds, nnratio, claimed):
         f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)

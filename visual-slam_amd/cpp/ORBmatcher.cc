@@ -116,6 +116,91 @@ int ORBmatcher::SearchByProjection(const FrameView& F, const std::vector<Project
     return nmatches;
 }
 
+namespace {
+// DBoW2::FeatureVector -> orbx_feature_vector (std::map iterates node ids in ascending order)
+struct FlatFeatureVector {
+    std::vector<uint32_t> ids; std::vector<int32_t> ptr, feat; orbx_feature_vector fv;
+    explicit FlatFeatureVector(const FeatureVectorMap& m)
+    {
+        ptr.push_back(0);
+        for (const auto& kv : m) {
+            ids.push_back(kv.first);
+            for (unsigned int i : kv.second) feat.push_back((int32_t)i);
+            ptr.push_back((int32_t)feat.size());
+        }
+        fv.node_ids = ids.data(); fv.node_ptr = ptr.data(); fv.features = feat.data(); fv.n_nodes = (int32_t)ids.size();
+    }
+};
+std::vector<unsigned char> flags(const std::vector<bool>& v, size_t n)
+{
+    std::vector<unsigned char> o(n, 0);
+    for (size_t i = 0; i < n && i < v.size(); ++i) o[i] = v[i] ? 1 : 0;
+    return o;
+}
+std::vector<float> angles(const std::vector<cv::KeyPoint>& k)
+{
+    std::vector<float> a(k.size());
+    for (size_t i = 0; i < k.size(); ++i) a[i] = k[i].angle;
+    return a;
+}
+} // namespace
+
+int ORBmatcher::SearchByBoW(const FrameView& KF, const std::vector<bool>& vbGoodMapPointKF, const FeatureVectorMap& vFeatVecKF,
+                            const FrameView& F, const std::vector<cv::KeyPoint>& vKeysF, const FeatureVectorMap& vFeatVecF,
+                            std::vector<int>& vnMatchesF)
+{
+    const int n1 = (int)KF.keysUn->size(), n2 = (int)vKeysF.size();
+    std::vector<unsigned char> d1 = packed_rows(*KF.descriptors), d2 = packed_rows(*F.descriptors), e1 = flags(vbGoodMapPointKF, n1);
+    std::vector<float> a1 = angles(*KF.keysUn), a2 = angles(vKeysF);
+    FlatFeatureVector f1(vFeatVecKF), f2(vFeatVecF);
+    std::vector<int> m12(n1, -1);
+    vnMatchesF.assign(n2, -1);
+    int nmatches = 0;
+    check(orbx_search_by_bow(Context(), d1.data(), a1.data(), e1.data(), n1, &f1.fv, d2.data(), a2.data(), nullptr, n2, &f2.fv,
+                             mfNNratio, mbCheckOrientation ? 1 : 0, 0, m12.data(), vnMatchesF.data(), &nmatches), "SearchByBoW");
+    return nmatches;
+}
+
+int ORBmatcher::SearchByBoW(const FrameView& KF1, const std::vector<bool>& vbGoodMapPoint1, const FeatureVectorMap& vFeatVec1,
+                            const FrameView& KF2, const std::vector<bool>& vbGoodMapPoint2, const FeatureVectorMap& vFeatVec2,
+                            std::vector<int>& vnMatches12)
+{
+    const int n1 = (int)KF1.keysUn->size(), n2 = (int)KF2.keysUn->size();
+    std::vector<unsigned char> d1 = packed_rows(*KF1.descriptors), d2 = packed_rows(*KF2.descriptors);
+    std::vector<unsigned char> e1 = flags(vbGoodMapPoint1, n1), e2 = flags(vbGoodMapPoint2, n2);
+    std::vector<float> a1 = angles(*KF1.keysUn), a2 = angles(*KF2.keysUn);
+    FlatFeatureVector f1(vFeatVec1), f2(vFeatVec2);
+    std::vector<int> m21(n2, -1);
+    vnMatches12.assign(n1, -1);
+    int nmatches = 0;
+    check(orbx_search_by_bow(Context(), d1.data(), a1.data(), e1.data(), n1, &f1.fv, d2.data(), a2.data(), e2.data(), n2, &f2.fv,
+                             mfNNratio, mbCheckOrientation ? 1 : 0, 1, vnMatches12.data(), m21.data(), &nmatches), "SearchByBoW");
+    return nmatches;
+}
+
+int ORBmatcher::SearchForTriangulation(const FrameView& KF1, const std::vector<bool>& vbMapPoint1, const FeatureVectorMap& vFeatVec1,
+                                       const FrameView& KF2, const std::vector<bool>& vbMapPoint2, const FeatureVectorMap& vFeatVec2,
+                                       const float F12[9], float ex, float ey, const std::vector<float>& vScaleFactors2,
+                                       const std::vector<float>& vLevelSigma2_2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                                       const bool bOnlyStereo)
+{
+    const int n1 = (int)KF1.keysUn->size(), n2 = (int)KF2.keysUn->size();
+    if (!KF1.uRight || !KF2.uRight) throw std::runtime_error("SearchForTriangulation: FrameView::uRight (mvuRight) is required");
+    std::vector<unsigned char> d1 = packed_rows(*KF1.descriptors), d2 = packed_rows(*KF2.descriptors);
+    std::vector<unsigned char> h1 = flags(vbMapPoint1, n1), h2 = flags(vbMapPoint2, n2);
+    FlatFeatureVector f1(vFeatVec1), f2(vFeatVec2);
+    std::vector<int> m12(n1, -1);
+    int nmatches = 0;
+    check(orbx_search_for_triangulation(Context(), as_orbx(*KF1.keysUn), d1.data(), h1.data(), KF1.uRight->data(), n1, &f1.fv,
+                                        as_orbx(*KF2.keysUn), d2.data(), h2.data(), KF2.uRight->data(), n2, &f2.fv, F12, ex, ey,
+                                        vScaleFactors2.data(), vLevelSigma2_2.data(), (int)vScaleFactors2.size(), bOnlyStereo ? 1 : 0,
+                                        mbCheckOrientation ? 1 : 0, m12.data(), &nmatches), "SearchForTriangulation");
+    vMatchedPairs.clear();                                                       // :815-823
+    vMatchedPairs.reserve(nmatches);
+    for (int i = 0; i < n1; ++i) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
+    return nmatches;
+}
+
 void ORBmatcher::StereoRowSearch(const std::vector<cv::KeyPoint>& vKeysLeft, const cv::Mat& descLeft,
                                  const std::vector<cv::KeyPoint>& vKeysRight, const cv::Mat& descRight,
                                  const std::vector<float>& vScaleFactors, int nRows, float minD, float maxD,

@@ -6,6 +6,8 @@
 #ifndef ORBX_ORBMATCHER_H
 #define ORBX_ORBMATCHER_H
 
+#include <map>
+#include <utility>
 #include <vector>
 #include "cv_compat.h"
 #include "ORBextractor.h"
@@ -33,6 +35,10 @@ struct ProjectedQuery {
     const unsigned char* descriptor; // 32 bytes
 };
 
+// What DBoW2::FeatureVector is (Thirdparty/DBoW2/DBoW2/FeatureVector.h:21-22): node id -> indices of the features under it.
+// A DBoW2::FeatureVector converts to this reference implicitly.
+typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVectorMap;
+
 class ORBmatcher
 {
 public:
@@ -56,6 +62,27 @@ public:
     // mode 0: levels level-1..level+1, 1: forward motion (>= level), 2: backward (0..level).
     int SearchByProjection(const FrameView& CurrentFrame, const std::vector<ProjectedQuery>& vQueries, std::vector<int>& vnClaimed,
                            int mode, int thDist);
+
+    // src/ORBmatcher.cc:159-291, SearchByBoW(KeyFrame*, Frame&, ...).  vbGoodMapPointKF[i]: key-frame feature i has a map
+    // point that is not bad; vKeysF = F.mvKeys (the reference takes the frame's angles from there, :241).
+    // vnMatchesF[iF] = key-frame feature whose map point the reference stores in vpMapPointMatches[iF], or -1.
+    int SearchByBoW(const FrameView& KF, const std::vector<bool>& vbGoodMapPointKF, const FeatureVectorMap& vFeatVecKF,
+                    const FrameView& F, const std::vector<cv::KeyPoint>& vKeysF, const FeatureVectorMap& vFeatVecF,
+                    std::vector<int>& vnMatchesF);
+
+    // src/ORBmatcher.cc:525-658, SearchByBoW(KeyFrame*, KeyFrame*, ...).  vnMatches12[i1] = feature of key frame 2 whose
+    // map point the reference stores in vpMatches12[i1], or -1.
+    int SearchByBoW(const FrameView& KF1, const std::vector<bool>& vbGoodMapPoint1, const FeatureVectorMap& vFeatVec1,
+                    const FrameView& KF2, const std::vector<bool>& vbGoodMapPoint2, const FeatureVectorMap& vFeatVec2,
+                    std::vector<int>& vnMatches12);
+
+    // src/ORBmatcher.cc:660-826.  vbMapPoint: the feature has a map point (any); FrameView::uRight must be set (mvuRight).
+    // F12 row-major; (ex, ey) the epipole in image 2 (:667-673); scale factors and level sigma^2 of key frame 2.
+    int SearchForTriangulation(const FrameView& KF1, const std::vector<bool>& vbMapPoint1, const FeatureVectorMap& vFeatVec1,
+                               const FrameView& KF2, const std::vector<bool>& vbMapPoint2, const FeatureVectorMap& vFeatVec2,
+                               const float F12[9], float ex, float ey, const std::vector<float>& vScaleFactors2,
+                               const std::vector<float>& vLevelSigma2_2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                               const bool bOnlyStereo);
 
     // Frame::ComputeStereoMatches, Hamming part (src/Frame.cc:466-549).
     void StereoRowSearch(const std::vector<cv::KeyPoint>& vKeysLeft, const cv::Mat& descLeft,

@@ -224,3 +224,188 @@ int orbx_search_by_projection_lastframe(orbx_matcher* m, const float* qu, const 
 }
 
 } // extern "C"
+
+namespace {
+
+// Walk of two feature vectors in step (src/ORBmatcher.cc:183-267): calls f(k1, k2) for every node id both hold.
+// (lower_bound on the map is a jump to the first node id not below the other side's; a linear merge visits the same pairs.)
+template <class F>
+void for_shared_nodes(const orbx_feature_vector& a, const orbx_feature_vector& b, F&& f)
+{
+    int i = 0, j = 0;
+    while (i < a.n_nodes && j < b.n_nodes) {
+        if (a.node_ids[i] == b.node_ids[j]) { f(i, j); ++i; ++j; }
+        else if (a.node_ids[i] < b.node_ids[j]) ++i;
+        else ++j;
+    }
+}
+
+bool feature_vector_ok(const orbx_feature_vector* fv, int n)
+{
+    if (!fv || fv->n_nodes < 0) return false;
+    if (fv->n_nodes == 0) return true;
+    if (!fv->node_ids || !fv->node_ptr || fv->node_ptr[0] != 0) return false;
+    for (int k = 0; k < fv->n_nodes; ++k) {
+        if (fv->node_ptr[k + 1] < fv->node_ptr[k]) return false;
+        if (k > 0 && fv->node_ids[k] <= fv->node_ids[k - 1]) return false;
+    }
+    if (fv->node_ptr[fv->n_nodes] > 0 && !fv->features) return false;
+    for (int c = 0; c < fv->node_ptr[fv->n_nodes]; ++c) if (fv->features[c] < 0 || fv->features[c] >= n) return false;
+    return true;
+}
+
+// One CSR row per side-1 feature that takes part, in processing order; the row's candidates are the side-2 list of the node.
+struct BowRows {
+    Csr csr;
+    std::vector<int> idx1;            // side-1 feature of each row
+    std::vector<uint8_t> q;           // its descriptor, gathered
+    template <class Take>
+    void build(const orbx_feature_vector& fv1, const orbx_feature_vector& fv2, const uint8_t* d1, Take&& take)
+    {
+        csr.start(0);
+        std::vector<int> v;
+        for_shared_nodes(fv1, fv2, [&](int a, int b) {
+            v.assign(fv2.features + fv2.node_ptr[b], fv2.features + fv2.node_ptr[b + 1]);
+            for (int c = fv1.node_ptr[a]; c < fv1.node_ptr[a + 1]; ++c) {
+                const int i1 = fv1.features[c];
+                if (!take(i1)) continue;
+                idx1.push_back(i1);
+                q.insert(q.end(), d1 + (size_t)i1 * 32, d1 + (size_t)i1 * 32 + 32);
+                csr.push_row(v);
+            }
+        });
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+// ORBmatcher::SearchByBoW, src/ORBmatcher.cc:159-291 (keyframe_form 0) and :525-658 (keyframe_form 1)
+int orbx_search_by_bow(orbx_matcher* m,
+                       const uint8_t* d1, const float* angle1, const uint8_t* eligible1, int n1, const orbx_feature_vector* fv1,
+                       const uint8_t* d2, const float* angle2, const uint8_t* eligible2, int n2, const orbx_feature_vector* fv2,
+                       float nnratio, int check_ori, int keyframe_form, int32_t* match12, int32_t* match21, int* nmatches)
+{
+    if (!m || !nmatches || n1 < 0 || n2 < 0) { set_error("orbx_search_by_bow: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if ((n1 > 0 && (!d1 || !angle1 || !eligible1 || !match12)) || (n2 > 0 && (!d2 || !angle2 || !match21))) { set_error("orbx_search_by_bow: null pointer"); return ORBX_ERR_BAD_ARG; }
+    if (!feature_vector_ok(fv1, n1) || !feature_vector_ok(fv2, n2)) { set_error("orbx_search_by_bow: malformed feature vector"); return ORBX_ERR_BAD_ARG; }
+    *nmatches = 0;
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    for (int i = 0; i < n2; ++i) match21[i] = -1;
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    BowRows rows;
+    rows.build(*fv1, *fv2, d1, [&](int i1) { return eligible1[i1] != 0; });
+    const int nr = (int)rows.idx1.size();
+    if (nr == 0) return ORBX_OK;
+    int rc = rows.csr.run(m, rows.q.data(), nr, d2, n2);
+    if (rc) return rc;
+
+    int count = 0;
+    std::vector<std::pair<int, int>> hist[HISTO_LENGTH];
+    for (int r = 0; r < nr; ++r) {
+        const int i1 = rows.idx1[r];
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int c = rows.csr.rowptr[r]; c < rows.csr.rowptr[r + 1]; ++c) {
+            const int i2 = rows.csr.cand[c];
+            if (match21[i2] >= 0 || (eligible2 && !eligible2[i2])) continue;     // :212 / :579
+            const int dist = rows.csr.dist[c];
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        const bool low = keyframe_form ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW;  // :601 / :231
+        if (low && (float)bestDist1 < nnratio * (float)bestDist2) {
+            match12[i1] = bestIdx2; match21[bestIdx2] = i1; ++count;
+            if (check_ori) hist[rotation_bin(angle1[i1], angle2[bestIdx2])].push_back({i1, bestIdx2});
+        }
+    }
+    if (check_ori) {
+        int32_t sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; ++i) sizes[i] = (int32_t)hist[i].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orbx_compute_three_maxima(sizes, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (const auto& pr : hist[i]) { match12[pr.first] = -1; match21[pr.second] = -1; --count; }
+        }
+    }
+    *nmatches = count;
+    return ORBX_OK;
+}
+
+// ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:660-826
+int orbx_search_for_triangulation(orbx_matcher* m,
+                                  const orbx_keypoint* k1, const uint8_t* d1, const uint8_t* has_mp1, const float* uright1, int n1,
+                                  const orbx_feature_vector* fv1,
+                                  const orbx_keypoint* k2, const uint8_t* d2, const uint8_t* has_mp2, const float* uright2, int n2,
+                                  const orbx_feature_vector* fv2,
+                                  const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                  int nlevels, int only_stereo, int check_ori, int32_t* match12, int* nmatches)
+{
+    if (!m || !nmatches || n1 < 0 || n2 < 0 || !F12 || !scale_factors2 || !level_sigma2_2 || nlevels < 1 || nlevels > kMaxLevels) {
+        set_error("orbx_search_for_triangulation: bad argument"); return ORBX_ERR_BAD_ARG;
+    }
+    if ((n1 > 0 && (!k1 || !d1 || !has_mp1 || !uright1 || !match12)) || (n2 > 0 && (!k2 || !d2 || !has_mp2 || !uright2))) {
+        set_error("orbx_search_for_triangulation: null pointer"); return ORBX_ERR_BAD_ARG;
+    }
+    if (!feature_vector_ok(fv1, n1) || !feature_vector_ok(fv2, n2)) { set_error("orbx_search_for_triangulation: malformed feature vector"); return ORBX_ERR_BAD_ARG; }
+    for (int i = 0; i < n2; ++i) if (k2[i].octave < 0 || k2[i].octave >= nlevels) { set_error("orbx_search_for_triangulation: octave out of range"); return ORBX_ERR_BAD_ARG; }
+    *nmatches = 0;
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    BowRows rows;
+    rows.build(*fv1, *fv2, d1, [&](int i1) { return !has_mp1[i1] && (!only_stereo || uright1[i1] >= 0); });   // :702-712
+    const int nr = (int)rows.idx1.size();
+    if (nr == 0) return ORBX_OK;
+    int rc = rows.csr.run(m, rows.q.data(), nr, d2, n2);
+    if (rc) return rc;
+
+    int count = 0;
+    std::vector<int> hist[HISTO_LENGTH];
+    for (int r = 0; r < nr; ++r) {
+        const int i1 = rows.idx1[r];
+        const bool bStereo1 = uright1[i1] >= 0;
+        const orbx_keypoint& kp1 = k1[i1];
+        // epipolar line of kp1 in image 2 (CheckDistEpipolarLine, :143-145)
+        const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+        const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+        const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+        const float den = a * a + b * b;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int cc = rows.csr.rowptr[r]; cc < rows.csr.rowptr[r + 1]; ++cc) {
+            const int i2 = rows.csr.cand[cc];
+            if (has_mp2[i2]) continue;                                           // :728 (vbMatched2 is never set)
+            const bool bStereo2 = uright2[i2] >= 0;
+            if (only_stereo && !bStereo2) continue;
+            const int dist = rows.csr.dist[cc];
+            if (dist > TH_LOW || dist > bestDist) continue;
+            const orbx_keypoint& kp2 = k2[i2];
+            if (!bStereo1 && !bStereo2) {
+                const float distex = ex - kp2.x, distey = ey - kp2.y;
+                if (distex * distex + distey * distey < 100 * scale_factors2[kp2.octave]) continue;
+            }
+            const float num = a * kp2.x + b * kp2.y + c;
+            if (den == 0) continue;
+            const float dsqr = num * num / den;
+            if (dsqr < 3.84 * level_sigma2_2[kp2.octave]) { bestIdx2 = i2; bestDist = dist; }   // double comparison, as written
+        }
+        if (bestIdx2 >= 0) {
+            match12[i1] = bestIdx2; ++count;
+            if (check_ori) hist[rotation_bin(kp1.angle, k2[bestIdx2].angle)].push_back(i1);
+        }
+    }
+    if (check_ori) {
+        int32_t sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; ++i) sizes[i] = (int32_t)hist[i].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orbx_compute_three_maxima(sizes, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int i1 : hist[i]) { match12[i1] = -1; --count; }
+        }
+    }
+    *nmatches = count;
+    return ORBX_OK;
+}
+
+} // extern "C"
