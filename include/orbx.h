@@ -192,6 +192,17 @@ int orbx_search_by_projection_lastframe(orbx_matcher* m,
                                         float minX, float maxX, float minY, float maxY,
                                         int mode, int th_dist, int check_ori, int32_t* claimed, int* nmatches);
 
+/* ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>& vpMatched, th),
+ * candidate loop and acceptance (src/ORBmatcher.cc:362-401).  Query i = one projected map point that passed the
+ * reference's visibility tests: projection (qu,qv), radius th*scale[level] (:363), predicted level, descriptor.
+ * claimed[n2]: -1 free, >= 0 taken (vpMatched[idx] non-null, :378); a match stores the query index (:399).
+ * Best-1 among free key-frame features of level-1..level, accepted when <= TH_LOW. */
+int orbx_search_by_projection_keyframe(orbx_matcher* m,
+                                       const float* qu, const float* qv, const float* qradius, const int32_t* qlevel,
+                                       const uint8_t* qdesc, int nq,
+                                       const orbx_keypoint* k2, const uint8_t* d2, int n2,
+                                       float minX, float maxX, float minY, float maxY, int32_t* claimed, int* nmatches);
+
 /* A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) flattened: node ids ascending, the feature
  * indices of node k in features[node_ptr[k] .. node_ptr[k+1]) in their list order. */
 typedef struct orbx_feature_vector {

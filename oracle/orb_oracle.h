@@ -122,6 +122,11 @@ void  orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
                        const float* scale_factors, int nlevels, int n_rows,
                        float min_d, float max_d, int32_t* best_dist, int32_t* best_idx);
 
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) candidate loop, src/ORBmatcher.cc:362-401 */
+int   orc_search_by_projection_keyframe(const float* qu, const float* qv, const float* qradius, const int32_t* qlevel,
+                                        const uint8_t* qdesc, int nq, const orc_keypoint* k2, const uint8_t* d2, int n2,
+                                        float minX, float maxX, float minY, float maxY, int32_t* claimed);
+
 /* DBoW2::FeatureVector flattened: node ids ascending; features of node k at features[node_ptr[k]..node_ptr[k+1]). */
 typedef struct orc_feature_vector {
     const uint32_t* node_ids; const int32_t* node_ptr; const int32_t* features; int32_t n_nodes;

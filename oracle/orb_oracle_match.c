@@ -495,3 +495,31 @@ int orc_search_for_triangulation(const orc_keypoint* k1, const uint8_t* d1, cons
     for (int i = 0; i < HISTO_LENGTH; ++i) free(rotHist[i]);
     return nmatches;
 }
+
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:362-401 */
+int orc_search_by_projection_keyframe(const float* qu, const float* qv, const float* qradius, const int32_t* qlevel,
+                                      const uint8_t* qdesc, int nq, const orc_keypoint* k2, const uint8_t* d2, int n2,
+                                      float minX, float maxX, float minY, float maxY, int32_t* claimed)
+{
+    int nmatches = 0;
+    orc_frame_grid* g = orc_grid_create(k2, n2, minX, maxX, minY, maxY);
+    int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n2 + 1));
+    for (int i = 0; i < nq; ++i) {
+        const int nPredictedLevel = qlevel[i];
+        int nc = orc_grid_features_in_area(g, qu[i], qv[i], qradius[i], 0, -1, vIndices, n2);      /* :365, no level filter */
+        if (nc == 0) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int idx = vIndices[c];
+            if (claimed[idx] >= 0) continue;
+            const int kpLevel = k2[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = orc_descriptor_distance(qdesc + (size_t)i * 32, d2 + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { claimed[bestIdx] = i; nmatches++; }
+    }
+    free(vIndices);
+    orc_grid_destroy(g);
+    return nmatches;
+}

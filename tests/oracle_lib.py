@@ -245,6 +245,20 @@ def search_for_initialization(k1, d1, k2, d2, bounds, prev_matched, window=100, 
     return m12, n, prev
 
 
+def search_by_projection_keyframe(qu, qv, qradius, qlevel, qdesc, k2, d2, bounds, claimed):
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    qu, qv, qradius = f32(qu), f32(qv), f32(qradius)
+    qlevel = np.ascontiguousarray(qlevel, np.int32)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+    claimed = np.ascontiguousarray(claimed, np.int32).copy()
+    lib.orc_search_by_projection_keyframe.restype = C.c_int
+    lib.orc_search_by_projection_keyframe.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp]
+    n = lib.orc_search_by_projection_keyframe(_ptr(qu), _ptr(qv), _ptr(qradius), _ptr(qlevel), _ptr(qdesc), len(qu), _ptr(k2), _ptr(d2),
+                                              len(k2), bounds[0], bounds[1], bounds[2], bounds[3], _ptr(claimed))
+    return claimed, n
+
+
 class FeatureVectorC(C.Structure):
     _fields_ = [("node_ids", _vp), ("node_ptr", _vp), ("features", _vp), ("n_nodes", C.c_int32)]
 

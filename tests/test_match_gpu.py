@@ -254,3 +254,19 @@ def test_search_for_triangulation(vsa, oracle, matcher, motion_features, only_st
                                             only_stereo, check_ori)
         assert g[1] == o[1] and np.array_equal(g[0], o[0])
         assert g[1] > 10
+
+
+def test_search_by_projection_keyframe(vsa, oracle, matcher, motion_features):
+    """The loop-closing form: map points projected with a Sim3 into a key frame, best-1 within TH_LOW."""
+    w, h, k1, d1, k2, d2 = motion_features
+    rng = np.random.default_rng(11)
+    sel = rng.permutation(len(k1))[:1200]
+    scale = vsa.scale_tables(vsa.make_params(2000))["scale"]
+    qu = k1["x"][sel] + 5.0 + rng.normal(0, 1.0, len(sel)).astype(np.float32)      # the second view is the first shifted by (5, 3)
+    qv = k1["y"][sel] + 3.0 + rng.normal(0, 1.0, len(sel)).astype(np.float32)
+    qlevel = np.clip(k1["octave"][sel] + rng.integers(0, 2, len(sel)), 0, 7).astype(np.int32)
+    qradius = (10.0 * scale[qlevel]).astype(np.float32)
+    claimed = np.where(rng.random(len(k2)) < 0.2, 1 << 20, -1).astype(np.int32)       # features already matched before the call
+    g = matcher.search_by_projection_keyframe(qu, qv, qradius, qlevel, d1[sel], k2, d2, (0.0, float(w), 0.0, float(h)), claimed)
+    o = oracle.search_by_projection_keyframe(qu, qv, qradius, qlevel, d1[sel], k2, d2, (0.0, float(w), 0.0, float(h)), claimed)
+    assert g[1] == o[1] and np.array_equal(g[0], o[0]) and g[1] > 100

@@ -63,6 +63,7 @@ _SIGS = {
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _pd]),
     "orbx_pyramid_level_device": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd)]),
     "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _pd]),
+    "orbx_search_by_projection_keyframe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, C.POINTER(_i)]),
     "orbx_search_by_bow": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "orbx_search_for_triangulation": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp,
                                            _i, _i, _i, _vp, C.POINTER(_i)]),
@@ -354,6 +355,19 @@ class Matcher:
                                                   bounds[0], bounds[1], bounds[2], bounds[3], _ptr(prev), window, nnratio,
                                                   int(check_ori), _ptr(m12), C.byref(n)))
         return m12, n.value, prev
+
+    def search_by_projection_keyframe(self, qu, qv, qradius, qlevel, qdesc, k2, d2, bounds, claimed):
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        qu, qv, qradius = f32(qu), f32(qv), f32(qradius)
+        qlevel = np.ascontiguousarray(qlevel, np.int32)
+        qdesc = np.ascontiguousarray(qdesc, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+        claimed = np.ascontiguousarray(claimed, np.int32).copy()
+        n = C.c_int()
+        _check(lib.orbx_search_by_projection_keyframe(self.h, _ptr(qu), _ptr(qv), _ptr(qradius), _ptr(qlevel), _ptr(qdesc), len(qu),
+                                                      _ptr(k2), _ptr(d2), len(k2), bounds[0], bounds[1], bounds[2], bounds[3],
+                                                      _ptr(claimed), C.byref(n)))
+        return claimed, n.value
 
     def search_by_bow(self, d1, angle1, eligible1, nodes1, d2, angle2, eligible2, nodes2, nnratio=0.7, check_ori=True, keyframe_form=0):
         d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)

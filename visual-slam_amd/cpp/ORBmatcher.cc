@@ -1,4 +1,5 @@
 #include "ORBmatcher.h"
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <cstring>
@@ -144,6 +145,26 @@ std::vector<float> angles(const std::vector<cv::KeyPoint>& k)
     return a;
 }
 } // namespace
+
+int ORBmatcher::SearchByProjectionKeyFrame(const FrameView& KF, const std::vector<ProjectedQuery>& vQueries, std::vector<int>& vnClaimed)
+{
+    const int n2 = (int)KF.keysUn->size(), nq = (int)vQueries.size();
+    vnClaimed.resize(n2, -1);
+    if (nq == 0 || n2 == 0) return 0;
+    std::vector<float> u(nq), v(nq), r(nq);
+    std::vector<int> level(nq);
+    std::vector<unsigned char> desc((size_t)nq * 32);
+    for (int i = 0; i < nq; ++i) {
+        u[i] = vQueries[i].u; v[i] = vQueries[i].v; r[i] = vQueries[i].radius; level[i] = vQueries[i].level;
+        std::copy(vQueries[i].descriptor, vQueries[i].descriptor + 32, desc.begin() + (size_t)i * 32);
+    }
+    std::vector<unsigned char> d2 = packed_rows(*KF.descriptors);
+    int nmatches = 0;
+    check(orbx_search_by_projection_keyframe(Context(), u.data(), v.data(), r.data(), level.data(), desc.data(), nq, as_orbx(*KF.keysUn),
+                                             d2.data(), n2, KF.minX, KF.maxX, KF.minY, KF.maxY, vnClaimed.data(), &nmatches),
+          "SearchByProjection");
+    return nmatches;
+}
 
 int ORBmatcher::SearchByBoW(const FrameView& KF, const std::vector<bool>& vbGoodMapPointKF, const FeatureVectorMap& vFeatVecKF,
                             const FrameView& F, const std::vector<cv::KeyPoint>& vKeysF, const FeatureVectorMap& vFeatVecF,

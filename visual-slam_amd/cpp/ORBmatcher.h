@@ -63,6 +63,11 @@ public:
     int SearchByProjection(const FrameView& CurrentFrame, const std::vector<ProjectedQuery>& vQueries, std::vector<int>& vnClaimed,
                            int mode, int thDist);
 
+    // src/ORBmatcher.cc:293-406, SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th): candidate loop and acceptance
+    // (best-1 within TH_LOW among free features of level-1..level).  ProjectedQuery::radius = th * scale[level];
+    // uRight and angle are not used.  vnClaimed as above.
+    int SearchByProjectionKeyFrame(const FrameView& KF, const std::vector<ProjectedQuery>& vQueries, std::vector<int>& vnClaimed);
+
     // src/ORBmatcher.cc:159-291, SearchByBoW(KeyFrame*, Frame&, ...).  vbGoodMapPointKF[i]: key-frame feature i has a map
     // point that is not bad; vKeysF = F.mvKeys (the reference takes the frame's angles from there, :241).
     // vnMatchesF[iF] = key-frame feature whose map point the reference stores in vpMapPointMatches[iF], or -1.

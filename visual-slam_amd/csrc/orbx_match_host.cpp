@@ -281,6 +281,43 @@ struct BowRows {
 
 extern "C" {
 
+// ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:362-401
+int orbx_search_by_projection_keyframe(orbx_matcher* m, const float* qu, const float* qv, const float* qradius, const int32_t* qlevel,
+                                       const uint8_t* qdesc, int nq, const orbx_keypoint* k2, const uint8_t* d2, int n2,
+                                       float minX, float maxX, float minY, float maxY, int32_t* claimed, int* nmatches)
+{
+    if (!m || !nmatches || nq < 0 || n2 < 0 || !(maxX > minX) || !(maxY > minY)) { set_error("orbx_search_by_projection_keyframe: bad argument"); return ORBX_ERR_BAD_ARG; }
+    *nmatches = 0;
+    if (nq == 0 || n2 == 0) return ORBX_OK;
+    if (!qu || !qv || !qradius || !qlevel || !qdesc || !k2 || !d2 || !claimed) { set_error("orbx_search_by_projection_keyframe: null pointer"); return ORBX_ERR_BAD_ARG; }
+    if (!octaves_ok(k2, n2)) { set_error("octave out of range"); return ORBX_ERR_BAD_ARG; }
+    FrameGrid grid;
+    grid.build(k2, n2, minX, maxX, minY, maxY);
+    Csr csr;
+    csr.start(nq);
+    std::vector<int> v;
+    for (int i = 0; i < nq; ++i) {
+        // GetFeaturesInArea(u, v, radius) and the level test of the loop (:365, :381-384) visit the same features in the
+        // same order as the level-filtered grid query
+        grid.query(qu[i], qv[i], qradius[i], qlevel[i] - 1, qlevel[i], v);
+        csr.push_row(v);
+    }
+    int rc = csr.run(m, qdesc, nq, d2, n2);
+    if (rc) return rc;
+    int count = 0;
+    for (int i = 0; i < nq; ++i) {
+        int bestDist = 256, bestIdx = -1;
+        for (int c = csr.rowptr[i]; c < csr.rowptr[i + 1]; ++c) {
+            const int idx = csr.cand[c];
+            if (claimed[idx] >= 0) continue;
+            if (csr.dist[c] < bestDist) { bestDist = csr.dist[c]; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { claimed[bestIdx] = i; ++count; }
+    }
+    *nmatches = count;
+    return ORBX_OK;
+}
+
 // ORBmatcher::SearchByBoW, src/ORBmatcher.cc:159-291 (keyframe_form 0) and :525-658 (keyframe_form 1)
 int orbx_search_by_bow(orbx_matcher* m,
                        const uint8_t* d1, const float* angle1, const uint8_t* eligible1, int n1, const orbx_feature_vector* fv1,
