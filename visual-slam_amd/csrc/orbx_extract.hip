@@ -389,7 +389,8 @@ template <int TS, int TR, int SS, int SR>
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
                                                     const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
                                                     uint32_t* __restrict__ cand, int cand_total,
-                                                    uint16_t* __restrict__ cellcnt, int ncells, int iniTh, int minTh, int n_frames)
+                                                    uint16_t* __restrict__ cellcnt, int ncells, const int32_t* __restrict__ list,
+                                                    int nlist, int iniTh, int minTh, int n_frames)
 {
     __shared__ __align__(16) uint8_t s_tile[4][TR * TS];
     __shared__ __align__(16) uint8_t s_score[4][SR * SS];
@@ -402,9 +403,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything derived from it stays scalar
     int frame; uint32_t blk;
-    if (!frame_chunk(blockIdx.x, (ncells + 3) >> 2, n_frames, frame, blk)) return;
-    const int cell = (int)blk * 4 + wave;
-    if (cell >= ncells) return;
+    if (!frame_chunk(blockIdx.x, (nlist + 3) >> 2, n_frames, frame, blk)) return;
+    if ((int)blk * 4 + wave >= nlist) return;
+    const int cell = list[(int)blk * 4 + wave];          // the cells this launch's tile size fits
     const CellRec c = cells[cell];
     const DevLevel& L = lv[c.level];
     const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + L.roi + (long long)c.y0 * L.stride + c.x0;
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 // dense key array (cell-row-major, raster inside a cell: the reference's vToDistributeKeys order),
 // then runs the level-synchronous DistributeOctTree of octree_algo.h.
 // ---------------------------------------------------------------------------------------------
-constexpr int kOctThreads = 256;     // more threads per quadtree were slower (512: +15 %, 1024: 2x at 640x480)
+constexpr int kOctThreads = 1024;    // launch bound; the launch uses orbx_extractor::oct_threads
 
 // LDS layout: the node tables of OtShared (capacity NC nodes), then room for KL keys (4 B) and node ids (2 B)
 __device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads)
@@ -1100,6 +1101,8 @@ struct orbx_extractor {
     std::vector<DevLevel> hlv;
     DevLevel* d_lv = nullptr;
     CellRec* d_cells = nullptr;
+    int32_t* d_cell_list = nullptr;   // cell indices: the n_small cells of at most kSmallCellDim pixels, then the n_big others
+    int n_small = 0, n_big = 0;
     ResizeX* d_rx = nullptr;
     ResizeY* d_ry = nullptr;
     ResizeGroupA* d_rga = nullptr;
@@ -1123,7 +1126,7 @@ struct orbx_extractor {
     int max_border_threads = 0;
     int NCmax = 0;
     int KL = 0;              // keys of one level that fit the quadtree's LDS key arrays
-    int oct_threads = kOctThreads;
+    int oct_threads = 256;
     size_t oct_lds = 0;
     int last_frames = 0;
     bool profiling = false;
@@ -1188,6 +1191,12 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         ex->KL = (int)std::max(0L, room / 6) / 128 * 128;
         if (ex->KL < 512) ex->KL = 0;
     }
+    // Workgroup size of the quadtree kernel: its key passes scale with the candidates of a level (~1 % of the pixels).
+    // Measured per batch: 640x480 256 threads 0.10 ms, 512 +15 %, 1024 2x; 3840x2160 256 threads 2.14 ms, 512 1.19, 1024 0.75.
+    {
+        const long px = (long)width * height;
+        ex->oct_threads = px >= 2000000 ? 1024 : px >= 1000000 ? 512 : 256;
+    }
     ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads, ex->KL);
     if (ex->oct_lds > 150 * 1024) { delete ex; set_error("per-level keypoint quota too large for the quadtree working set in LDS"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ex->oct_lds));
@@ -1199,6 +1208,15 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK(hipMalloc(&ex->d_ry, sizeof(ResizeY) * std::max<size_t>(geo.ry.size(), 1)));
     HIP_CHECK(hipMemcpy(ex->d_lv, ex->hlv.data(), sizeof(DevLevel) * geo.nlevels, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(ex->d_cells, geo.cells.data(), sizeof(CellRec) * geo.cells.size(), hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> small, big;
+        for (size_t i = 0; i < geo.cells.size(); ++i)
+            (std::max(geo.cells[i].cw, geo.cells[i].ch) <= kSmallCellDim ? small : big).push_back((int32_t)i);
+        ex->n_small = (int)small.size(); ex->n_big = (int)big.size();
+        small.insert(small.end(), big.begin(), big.end());
+        HIP_CHECK(hipMalloc(&ex->d_cell_list, sizeof(int32_t) * std::max<size_t>(small.size(), 1)));
+        if (!small.empty()) HIP_CHECK(hipMemcpy(ex->d_cell_list, small.data(), sizeof(int32_t) * small.size(), hipMemcpyHostToDevice));
+    }
     if (!geo.rx.empty()) HIP_CHECK(hipMemcpy(ex->d_rx, geo.rx.data(), sizeof(ResizeX) * geo.rx.size(), hipMemcpyHostToDevice));
     if (!geo.ry.empty()) HIP_CHECK(hipMemcpy(ex->d_ry, geo.ry.data(), sizeof(ResizeY) * geo.ry.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&ex->d_rga, sizeof(ResizeGroupA) * std::max<size_t>(geo.rga.size(), 1)));
@@ -1225,7 +1243,7 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_rx, ex->d_ry, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
+    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_cell_list, ex->d_rx, ex->d_ry, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
                     ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : ex->ev) if (e) (void)hipEventDestroy(e);
@@ -1274,16 +1292,17 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
     {
+        // cells up to 38 pixels (the usual 30..38) run with small LDS tiles and five workgroups per CU; the few larger
+        // ones (a level whose border-to-border span is just under a multiple of 30) get their own launch
         const int nc = (int)G.cells.size();
-        dim3 grid(frame_chunk_grid((nc + 3) / 4, B));
-        if (G.max_cell_dim <= kSmallCellDim)
-            hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 48, kSmallCellDim + 2>), grid, dim3(256), 0, st, pyr,
-                               (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, cand, G.cand_total, cellcnt, nc,
-                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
-        else
-            hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2>), grid, dim3(256), 0, st, pyr,
-                               (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, cand, G.cand_total, cellcnt, nc,
-                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
+        if (ex->n_small)
+            hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 48, kSmallCellDim + 2>), dim3(frame_chunk_grid((ex->n_small + 3) / 4, B)),
+                               dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, cand, G.cand_total, cellcnt, nc,
+                               ex->d_cell_list, ex->n_small, ex->params.ini_th_fast, ex->params.min_th_fast, B);
+        if (ex->n_big)
+            hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2>), dim3(frame_chunk_grid((ex->n_big + 3) / 4, B)),
+                               dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, cand, G.cand_total, cellcnt, nc,
+                               ex->d_cell_list + ex->n_small, ex->n_big, ex->params.ini_th_fast, ex->params.min_th_fast, B);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
     {
@@ -1550,7 +1569,7 @@ int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, in
     HIP_CHECK(hipMalloc(&d_n, sizeof(int32_t)));
     if (n) HIP_CHECK(hipMemcpy(d_keys, packed_keys, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree_single), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(kOctThreads), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL);
+    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(256), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL);
     HIP_CHECK(hipGetLastError());
     int32_t cnt = 0;
     HIP_CHECK(hipMemcpy(&cnt, d_n, sizeof(int32_t), hipMemcpyDeviceToHost));
