@@ -49,6 +49,10 @@ struct DevLevel {
     unsigned gpr_magic;
     int cpr;          // 16-byte chunks per ROI row, ceil(w/16)
     unsigned cpr_magic; // ceil(2^32 / cpr): row of flat chunk index i is umulhi(i, cpr_magic)
+    int tpr;            // 16-byte columns per row of the tiled blurred level
+    int upr;            // 16-pixel units per row of the blur kernel
+    unsigned upr_magic;
+    unsigned long long blur_offset;   // of the tiled blurred level inside one frame's blurred block
     int border_threads; // threads of k_borders for this level
     float inv_scale;    // mvInvScaleFactor[level]
 };
@@ -654,69 +658,98 @@ __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* _
 constexpr int kBlurRows = 16;
 struct __attribute__((packed, aligned(4))) u96 { uint32_t a, b, c; };
 
+// Output layout: every blurred level is tiled, 8 rows x 16 bytes per 128-byte tile (tile (y >> 3, x >> 4), row y & 7 at byte
+// 16 * (y & 7)), tpr tiles per tile row: the 37x37 window of a keypoint then spans ~19 cache lines instead of ~51.  A
+// wavefront's 64 threads are 16 units of 16 pixels x 16 rows; the results pass through LDS so that every store of the
+// wavefront writes eight complete lines (8 lanes x 16 bytes each).
+constexpr int kBlurUnitBytes = 16 * kBlurRows + 16;   // one unit in LDS, padded against bank conflicts
 template <int MODE>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
-                                              const DevLevel* __restrict__ lv, int nlevels, int blocks_per_level, int n_frames)
+                                              unsigned long long blur_bytes, const DevLevel* __restrict__ lv, int nlevels,
+                                              int blocks_per_level, int n_frames)
 {
+    __shared__ __align__(16) uint8_t s_stage[4][16 * kBlurUnitBytes];
     int frame; uint32_t chunk;
     if (!frame_chunk(blockIdx.x, (uint32_t)(nlevels * blocks_per_level), n_frames, frame, chunk)) return;
     const uint32_t level = chunk / (uint32_t)blocks_per_level, blk = chunk - level * (uint32_t)blocks_per_level;
     const DevLevel& L = lv[level];
-    const int gpr = (L.w + 3) >> 2;
-    const int strips = (L.h + kBlurRows - 1) / kBlurRows;
-    const int i = (int)blk * 256 + threadIdx.x;
-    if (i >= gpr * strips) return;
-    const int strip = i / gpr, g = i - strip * gpr;
-    const int y0 = strip * kBlurRows, x = 4 * g;
-    // wavefront-uniform bases (three rows up and four bytes left of the ROI origin for the source) plus a
-    // 32-bit lane offset
-    const unsigned long long fo = (unsigned long long)frame * pyr_bytes + L.roi;
-    const uint32_t stride = (uint32_t)L.stride;
-    const uint8_t* src = pyr + fo - 3 * stride - 4;
-    uint8_t* dst = blr + fo;
-    const uint32_t vo = __umul24((uint32_t)y0, stride) + (uint32_t)x;
-    const bool even_ties = MODE != 0 && x < (L.w & ~3);
-    constexpr uint32_t T0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), T1 = 49u | (34u << 8) | (18u << 16);
-    constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
-    constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
-    uint32_t P[4][4];               // last four row pairs: per pixel, sums of rows 2j | 2j+1 << 16
+    const uint32_t upr = (uint32_t)L.upr;                              // units (4 threads, 16 pixels) per strip row
+    const uint32_t strips = (uint32_t)((L.h + kBlurRows - 1) / kBlurRows);
+    const uint32_t nunits = upr * strips;
+    if (blk * 64u >= nunits) return;                                   // the whole workgroup is past the level
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t i = blk * 256 + threadIdx.x;                        // thread = (unit i >> 2, quarter i & 3)
+    uint8_t* stage = s_stage[wave];
+    if ((i >> 2) < nunits) {
+        uint32_t strip, uc;
+        split_index(i >> 2, upr, L.upr_magic, strip, uc);
+        const int y0 = (int)strip * kBlurRows, x = (int)(16 * uc + 4 * (i & 3));
+        // wavefront-uniform base (three rows up and four bytes left of the ROI origin) plus a 32-bit lane offset
+        const uint32_t stride = (uint32_t)L.stride;
+        const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + L.roi - 3 * stride - 4;
+        const uint32_t vo = __umul24((uint32_t)y0, stride) + (uint32_t)x;
+        const bool even_ties = MODE != 0 && x < (L.w & ~3);
+        uint32_t* out = reinterpret_cast<uint32_t*>(stage + ((lane >> 2) * kBlurUnitBytes + 4 * (lane & 3)));   // + 16 bytes per row
+        constexpr uint32_t T0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), T1 = 49u | (34u << 8) | (18u << 16);
+        constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
+        constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
+        uint32_t P[4][4];               // last four row pairs: per pixel, sums of rows 2j | 2j+1 << 16
 #pragma unroll
-    for (int j = 0; j < kBlurRows / 2 + 3; ++j) {
-        uint32_t h[2][4];
+        for (int j = 0; j < kBlurRows / 2 + 3; ++j) {
+            uint32_t h[2][4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const u96 t = *reinterpret_cast<const u96*>(src + (vo + (uint32_t)(2 * j + r) * stride));
-            h[r][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 1), T1,
-                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 1), T0, 0u, false), false);
-            h[r][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 2), T1,
-                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 2), T0, 0u, false), false);
-            h[r][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 3), T1,
-                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 3), T0, 0u, false), false);
-            h[r][3] = __builtin_amdgcn_udot4(t.c, T1, __builtin_amdgcn_udot4(t.b, T0, 0u, false), false);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) P[j & 3][k] = h[0][k] | (h[1][k] << 16);
-        if (j >= 3) {
-            const int m = j - 3;    // output rows 2m, 2m+1 of the strip: row pairs m .. m+3
-            uint32_t te[4], to[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#define ORBX_DOT2(a, w, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, (uint32_t)(a)), __builtin_bit_cast(us16x2, (uint32_t)(w)), acc, false)
-                const uint32_t d0 = P[m & 3][k], d1 = P[(m + 1) & 3][k], d2 = P[(m + 2) & 3][k], d3 = P[(m + 3) & 3][k];
-                const uint32_t se = ORBX_DOT2(d3, E3, ORBX_DOT2(d2, E2, ORBX_DOT2(d1, E1, ORBX_DOT2(d0, E0, 0u))));
-                const uint32_t so = ORBX_DOT2(d3, O3, ORBX_DOT2(d2, O2, ORBX_DOT2(d1, O1, ORBX_DOT2(d0, O0, 0u))));
-#undef ORBX_DOT2
-                te[k] = se + (even_ties ? 32767u + ((se >> 16) & 1u) : 32768u);
-                to[k] = so + (even_ties ? 32767u + ((so >> 16) & 1u) : 32768u);
+            for (int r = 0; r < 2; ++r) {
+                const u96 t = *reinterpret_cast<const u96*>(src + (vo + (uint32_t)(2 * j + r) * stride));
+                h[r][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 1), T1,
+                              __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 1), T0, 0u, false), false);
+                h[r][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 2), T1,
+                              __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 2), T0, 0u, false), false);
+                h[r][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 3), T1,
+                              __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 3), T0, 0u, false), false);
+                h[r][3] = __builtin_amdgcn_udot4(t.c, T1, __builtin_amdgcn_udot4(t.b, T0, 0u, false), false);
             }
-            // bits 16..24 of each sum hold the rounded value (at most 257): gather as 16-bit pairs, clamp, pack bytes
-            const us16x2 lim = {255, 255};
-            const uint32_t e01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[1], te[0], 0x07060302u)), lim));
-            const uint32_t e23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[3], te[2], 0x07060302u)), lim));
-            const uint32_t o01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[1], to[0], 0x07060302u)), lim));
-            const uint32_t o23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[3], to[2], 0x07060302u)), lim));
-            if (y0 + 2 * m < L.h) *reinterpret_cast<uint32_t*>(dst + (vo + (uint32_t)(2 * m) * stride)) = __builtin_amdgcn_perm(e23, e01, 0x06040200u);
-            if (y0 + 2 * m + 1 < L.h) *reinterpret_cast<uint32_t*>(dst + (vo + (uint32_t)(2 * m + 1) * stride)) = __builtin_amdgcn_perm(o23, o01, 0x06040200u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) P[j & 3][k] = h[0][k] | (h[1][k] << 16);
+            if (j >= 3) {
+                const int m = j - 3;    // output rows 2m, 2m+1 of the strip: row pairs m .. m+3
+                uint32_t te[4], to[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#define ORBX_DOT2(a, w, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, (uint32_t)(a)), __builtin_bit_cast(us16x2, (uint32_t)(w)), acc, false)
+                    const uint32_t d0 = P[m & 3][k], d1 = P[(m + 1) & 3][k], d2 = P[(m + 2) & 3][k], d3 = P[(m + 3) & 3][k];
+                    const uint32_t se = ORBX_DOT2(d3, E3, ORBX_DOT2(d2, E2, ORBX_DOT2(d1, E1, ORBX_DOT2(d0, E0, 0u))));
+                    const uint32_t so = ORBX_DOT2(d3, O3, ORBX_DOT2(d2, O2, ORBX_DOT2(d1, O1, ORBX_DOT2(d0, O0, 0u))));
+#undef ORBX_DOT2
+                    te[k] = se + (even_ties ? 32767u + ((se >> 16) & 1u) : 32768u);
+                    to[k] = so + (even_ties ? 32767u + ((so >> 16) & 1u) : 32768u);
+                }
+                // bits 16..24 of each sum hold the rounded value (at most 257): gather as 16-bit pairs, clamp, pack bytes
+                const us16x2 lim = {255, 255};
+                const uint32_t e01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[1], te[0], 0x07060302u)), lim));
+                const uint32_t e23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[3], te[2], 0x07060302u)), lim));
+                const uint32_t o01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[1], to[0], 0x07060302u)), lim));
+                const uint32_t o23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[3], to[2], 0x07060302u)), lim));
+                out[4 * (2 * m)] = __builtin_amdgcn_perm(e23, e01, 0x06040200u);
+                out[4 * (2 * m + 1)] = __builtin_amdgcn_perm(o23, o01, 0x06040200u);
+            }
+        }
+    }
+    wave_sync();
+    // lanes 8k..8k+7 store the eight 16-byte rows of one tile: unit c >> 4 of the wavefront, strip row c & 15
+    uint8_t* dst = blr + (unsigned long long)frame * blur_bytes + L.blur_offset;
+    const uint32_t tile_row_bytes = 128u * (uint32_t)L.tpr;
+    const uint32_t unit0 = (blk * 256u + 64u * (uint32_t)wave) >> 2;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const uint32_t c = 64u * s4 + (uint32_t)lane;
+        const uint32_t unit = unit0 + (c >> 4), r = c & 15u;
+        uint32_t strip, uc;
+        split_index(unit, upr, L.upr_magic, strip, uc);
+        const uint32_t y = strip * kBlurRows + r;
+        if (unit < nunits && y < (uint32_t)L.h) {
+            const uint4 v = *reinterpret_cast<const uint4*>(stage + ((c >> 4) * kBlurUnitBytes + 16 * r));
+            *reinterpret_cast<uint4*>(dst + (__umul24(y >> 3, tile_row_bytes) + 128u * uc + 16u * (y & 7u))) = v;
         }
     }
 }
@@ -820,7 +853,7 @@ __device__ __constant__ __align__(16) PatternF c_pattern_f = make_pattern_f();
 constexpr int kKpPerWave = 4;
 
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
-                                                  const DevLevel* __restrict__ lv, int nlevels,
+                                                  unsigned long long blur_bytes, const DevLevel* __restrict__ lv, int nlevels,
                                                   const uint32_t* __restrict__ lvlkp, int kp_total,
                                                   const int32_t* __restrict__ lvlcnt,
                                                   orbx_keypoint* __restrict__ okp, uint8_t* __restrict__ odesc,
@@ -885,12 +918,17 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         const int kx = (int)(jkey[q] >> 20) + kMinBorder, ky = (int)((jkey[q] >> 8) & 0xFFF) + kMinBorder;
         const uint32_t stride = (uint32_t)L.stride;
         const unsigned long long fo = (unsigned long long)frame * pyr_bytes + L.roi;
-        // blurred window rows ky-18..ky+18, the four aligned 16-byte chunks from the one holding column kx-18
-        // (ROI rows are 32-byte aligned)
-        const uint8_t* bsrc = blr + fo + (long long)(ky - 18) * L.stride + ((kx - 18) & ~15);
-        f.w0 = *reinterpret_cast<const u32x4*>(bsrc + (__umul24(wrow[0], stride) + wcol[0]));
-        f.w1 = *reinterpret_cast<const u32x4*>(bsrc + (__umul24(wrow[1], stride) + wcol[1]));
-        if (lane + 128 < kBlurW * kWinChunks) f.w2 = *reinterpret_cast<const u32x4*>(bsrc + (__umul24(wrow[2], stride) + wcol[2]));
+        // blurred window rows ky-18..ky+18, the four 16-byte columns from the one holding column kx-18, out of the
+        // tiled level: tile (y >> 3, column) holds row y at byte 16 * (y & 7)
+        const uint8_t* bsrc = blr + (unsigned long long)frame * blur_bytes + L.blur_offset + 128u * (uint32_t)((kx - 18) >> 4);
+        const uint32_t tile_row_bytes = 128u * (uint32_t)L.tpr;
+        auto tiled = [&](uint32_t r, uint32_t col16) __attribute__((always_inline)) {
+            const uint32_t y = (uint32_t)(ky - 18) + r;
+            return __umul24(y >> 3, tile_row_bytes) + 16u * (y & 7u) + 8u * col16;   // col16 = 16 * column index
+        };
+        f.w0 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[0], wcol[0]));
+        f.w1 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[1], wcol[1]));
+        if (lane + 128 < kBlurW * kWinChunks) f.w2 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[2], wcol[2]));
         // disc rows ky-15..ky+15 of the unblurred level, bytes kx-16..kx+15
         const uint8_t* csrc = pyr + fo + (long long)(ky - kHalfPatch) * L.stride + (kx - 16);
         if (disc_lane) {
@@ -1108,7 +1146,7 @@ struct orbx_extractor {
     ResizeGroupA* d_rga = nullptr;
     ResizeGroupB* d_rgb = nullptr;
     uint8_t* d_pyr = nullptr;
-    uint8_t* d_blur = nullptr;   // Gaussian-blurred copy of every level (ROI pixels only), same layout as d_pyr
+    uint8_t* d_blur = nullptr;   // Gaussian-blurred copy of every level (ROI pixels only), tiled for the descriptor windows
     int max_blur_threads = 0;
     int generic_levels = 0;  // levels produced by k_resize_generic
     uint32_t* d_cand = nullptr;
@@ -1173,10 +1211,11 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         d.fast_resize = g.fast_resize;
         if (l > 0 && !g.fast_resize) ++ex->generic_levels;
         d.rg_offset = g.rg_offset; d.gpr = g.gpr; d.gpr_magic = g.gpr_magic;
+        d.tpr = g.tpr; d.upr = g.upr; d.upr_magic = g.upr_magic; d.blur_offset = g.blur_offset;
         d.cpr = g.cpr; d.cpr_magic = g.cpr_magic;
         d.border_threads = border_threads(g.w, g.h, g.stride, kEdge, 8, 1 << 20);
         ex->max_border_threads = std::max(ex->max_border_threads, border_threads(g.w, g.h, g.stride, kFrameFill, 1, 2));
-        ex->max_blur_threads = std::max(ex->max_blur_threads, ((g.w + 3) / 4) * ((g.h + kBlurRows - 1) / kBlurRows));
+        ex->max_blur_threads = std::max(ex->max_blur_threads, 4 * g.upr * ((g.h + kBlurRows - 1) / kBlurRows));
         key_off += (g.cand_cap + 3) & ~3;
         ncmax = std::max(ncmax, g.kp_cap);
         ex->hlv[l] = d;
@@ -1225,8 +1264,8 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     if (!geo.rgb.empty()) HIP_CHECK(hipMemcpy(ex->d_rgb, geo.rgb.data(), sizeof(ResizeGroupB) * geo.rgb.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&ex->d_pyr, geo.pyr_bytes * B + 256));
     HIP_CHECK(hipMemset(ex->d_pyr, 0, geo.pyr_bytes * B + 256));
-    HIP_CHECK(hipMalloc(&ex->d_blur, geo.pyr_bytes * B + 256));
-    HIP_CHECK(hipMemset(ex->d_blur, 0, geo.pyr_bytes * B + 256));
+    HIP_CHECK(hipMalloc(&ex->d_blur, geo.blur_bytes * B + 256));
+    HIP_CHECK(hipMemset(ex->d_blur, 0, geo.blur_bytes * B + 256));
     HIP_CHECK(hipMalloc(&ex->d_cand, sizeof(uint32_t) * (size_t)geo.cand_total * B));
     HIP_CHECK(hipMalloc(&ex->d_cellcnt, sizeof(uint16_t) * geo.cells.size() * B));
     HIP_CHECK(hipMalloc(&ex->d_keys, sizeof(uint32_t) * (size_t)ex->key_total * B));
@@ -1260,7 +1299,7 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     d_images += (ptrdiff_t)f0 * frame_stride;
     d_kps += (size_t)f0 * cap_per_frame; d_desc += (size_t)f0 * cap_per_frame * 32; d_counts += f0;
     uint8_t* const pyr = ex->d_pyr + (size_t)f0 * G.pyr_bytes;
-    uint8_t* const blur = ex->d_blur + (size_t)f0 * G.pyr_bytes;
+    uint8_t* const blur = ex->d_blur + (size_t)f0 * G.blur_bytes;
     uint32_t* const cand = ex->d_cand + (size_t)f0 * G.cand_total;
     uint16_t* const cellcnt = ex->d_cellcnt + (size_t)f0 * G.cells.size();
     uint32_t* const keys = ex->d_keys + (size_t)f0 * ex->key_total;
@@ -1318,11 +1357,11 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
         const int bpl = (ex->max_blur_threads + 255) / 256;
         dim3 gblur(frame_chunk_grid((unsigned)(bpl * G.nlevels), B));
         if (ex->params.blur_rounding)
-            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels, bpl, B);
+            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels, bpl, B);
         else
-            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels, bpl, B);
+            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels, bpl, B);
         dim3 grid(frame_chunk_grid((G.kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), B));
-        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, ex->d_lv, G.nlevels,
+        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels,
                            lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
@@ -1500,7 +1539,13 @@ int orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* 
     if (dst_stride < L.w) return ORBX_ERR_BAD_ARG;
     HIP_CHECK(hipSetDevice(ex->device));
     HIP_CHECK(hipStreamSynchronize(ex->stream));
-    HIP_CHECK(hipMemcpy2D(dst, dst_stride, ex->d_blur + (size_t)frame * ex->geo.pyr_bytes + L.roi, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+    // the device copy is tiled (8 rows x 16 bytes per 128-byte tile, tpr tiles per tile row)
+    const size_t bytes = (size_t)((L.h + 7) / 8) * L.tpr * 128;
+    std::vector<uint8_t> tiled(bytes);
+    HIP_CHECK(hipMemcpy(tiled.data(), ex->d_blur + (size_t)frame * ex->geo.blur_bytes + L.blur_offset, bytes, hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.h; ++y)
+        for (int x = 0; x < L.w; ++x)
+            dst[(size_t)y * dst_stride + x] = tiled[((size_t)(y >> 3) * L.tpr + (x >> 4)) * 128 + 16 * (y & 7) + (x & 15)];
     return ORBX_OK;
 }
 

@@ -107,7 +107,7 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
     g.width = width; g.height = height; g.nlevels = p.nlevels;
     g.lv.assign(p.nlevels, LevelGeom());
     g.cells.clear(); g.rx.clear(); g.ry.clear(); g.rga.clear(); g.rgb.clear();
-    size_t off = 0;
+    size_t off = 0, boff = 0;
     int cand_off = 0, kp_off = 0;
     g.out_cap = 0; g.max_cell_dim = 0;
     const float W = 30; // src/ORBextractor.cc:768
@@ -133,6 +133,13 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
         L.offset = off;
         L.roi = off + (size_t)kEdge * L.stride + kRoiX;
         off += ((size_t)L.stride * L.rows + 255) & ~(size_t)255;
+        L.tpr = (L.w + 15) / 16 + 2;
+        L.upr = (L.w + 15) / 16;
+        L.upr_magic = (unsigned)((0x100000000ull + L.upr - 1) / L.upr);
+        for (uint32_t i = 0, n = (uint32_t)L.upr * (uint32_t)((L.h + 15) / 16) + 64; i < n; ++i)
+            if ((uint32_t)(((uint64_t)i * L.upr_magic) >> 32) != i / (uint32_t)L.upr) { set_error("internal: unit reciprocal inexact"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+        L.blur_offset = boff;
+        boff += (size_t)((L.h + 7) / 8) * L.tpr * 128;
 
         L.maxBorderX = L.w - kEdge + 3;        // :774-775
         L.maxBorderY = L.h - kEdge + 3;
@@ -228,6 +235,7 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
         }
     }
     g.pyr_bytes = off;
+    g.blur_bytes = boff;
     g.cand_total = cand_off;
     g.kp_total = kp_off;
     return ORBX_OK;

@@ -66,6 +66,10 @@ struct LevelGeom {
     unsigned gpr_magic;     // ceil(2^32 / gpr)
     int cpr;                // 16-byte chunks per row that the pyramid kernels write, ceil((w + kFrameFill)/16)
     unsigned cpr_magic;     // ceil(2^32 / cpr)
+    int tpr;                // 16-byte columns per row of the tiled blurred level, ceil(w/16) + 2
+    int upr;                // 16-pixel units per row that the blur kernel produces, ceil(w/16)
+    unsigned upr_magic;     // ceil(2^32 / upr)
+    size_t blur_offset;     // byte offset of the tiled blurred level inside one frame's blurred block
     float scale;            // mvScaleFactor[level]
     float kp_size;          // (float)(int)(31*scale), src/ORBextractor.cc:836,845
 };
@@ -80,6 +84,7 @@ struct Geometry {
     std::vector<ResizeGroupA> rga;
     std::vector<ResizeGroupB> rgb;
     size_t pyr_bytes = 0;     // one frame's pyramid block
+    size_t blur_bytes = 0;    // one frame's blurred block (every level tiled: 8 rows x 16 bytes per 128-byte tile)
     int cand_total = 0;       // one frame's candidate slots (u32)
     int kp_total = 0;         // one frame's per-level selected-keypoint slots
     int out_cap = 0;          // sum over levels of kp_cap
