@@ -157,16 +157,19 @@ def main():
     dom_ms = float(stage_ms[vsa.STAGES.index(dom)])
     achieved = stage_bytes[dom] * B / (dom_ms * 1e-3) / 1e9
     # HBM bytes per launch of that stage's kernels, measured with rocprofv3 --pmc on this workload (tools/pmc_traffic.py)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_issue = None, None, None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile) and (W, H, B, a.nfeatures, a.nlevels) == (640, 480, 256, 1000, 8):
         with open(tfile) as f:
             tj = json.load(f)
         if dom in tj.get("stages", {}):
             traffic, traffic_src = tj["stages"][dom], tj.get("source")
+        dom_kernel = {"fast": "k_fast_cells", "octree": "k_octree"}.get(dom)
+        valu_issue = tj.get("kernels_mean_per_launch", {}).get(dom_kernel, {}).get("valu_issue_frac") if dom_kernel else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(stage_bytes[dom] * B), "launch_ms": round(dom_ms, 4),
+                "valu_issue_frac": valu_issue,   # measured share of cycles issuing vector ALU work: what actually bounds this kernel
                 "pipeline_alg_bytes_per_frame": int(a_extract),
                 "pipeline_frac": round(a_extract * (fps / n_gpus) / HBM_PEAK, 4)}
 

@@ -9,7 +9,7 @@ import sys
 
 root = sys.argv[1]
 tab = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(f"{root}/*/*/*counter_collection.csv"):
+for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         m = re.search(r"\bk_[a-z0-9_]+", r["Kernel_Name"])
         if not m:

@@ -3,6 +3,7 @@
 `bench.py --contexts 1` (one launch of a kernel covers the whole 256-frame batch):
   pass 1: TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum   (read requests by size)
   pass 2: TCC_EA0_WRREQ_WRITE_DRAM_32B_sum                                    (written 32-byte units)
+  optional pass: SQ_INSTS_VALU GRBM_GUI_ACTIVE                                 (vector-ALU issue share per kernel)
 bytes read = 32*n32 + 64*n64 + 128*n128, bytes written = 32*units.  (FETCH_SIZE tallies gfx950's 128-byte
 requests at 64 bytes; the per-size counters do not.)  Writes profiles/traffic.json, keyed by bench.py's stages.
 usage: pmc_traffic.py <dir with the passes' counter_collection.csv> <out.json> [resize launches per step]"""
@@ -27,6 +28,10 @@ for k, d in mean.items():
     rd = 32 * d.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * d.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * d.get("TCC_EA0_RDREQ_128B_sum", 0)
     wr = 32 * d.get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", 0)
     kern[k] = {"read_bytes": int(rd), "write_bytes": int(wr)}
+    # share of the kernel's cycles in which its SIMDs issue vector ALU instructions: a wave64 VALU instruction occupies a
+    # SIMD for 4 cycles, the chip has 1024 SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    if "SQ_INSTS_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
+        kern[k]["valu_issue_frac"] = round(d["SQ_INSTS_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 3)
 tot = lambda k, n=1: n * (kern.get(k, {}).get("read_bytes", 0) + kern.get(k, {}).get("write_bytes", 0))
 stages = {"pyramid": tot("k_level0") + tot("k_resize", resizes) + tot("k_borders"), "fast": tot("k_fast_cells"),
           "octree": tot("k_octree"), "describe": tot("k_blur") + tot("k_describe")}
