@@ -429,13 +429,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                 *reinterpret_cast<uint4*>(tile + r * TS + 16 * j) = make_uint4(t.x, t.y, t.z, t.w);
             }
     }
-    const int gpr = (cw + 3) >> 2;                 // groups of four pixels per row (<= 15)
-    const int gsh = gpr <= 8 ? 3 : 4;
-    const int g = lane & ((1 << gsh) - 1);
-    const int rows_per_round = 64 >> gsh;
+    // pretest lanes: groups of four pixels, gpr per row (<= 15), as many whole rows per round as 64 lanes hold
+    const int gpr = (cw + 3) >> 2;
+    const int rows_per_round = 64 / gpr;
+    const int lrow = (lane * ((65536 + gpr - 1) / gpr)) >> 16;      // lane / gpr (exact for lane < 64, gpr <= 15)
+    const int g = lane - lrow * gpr;
     const int x = 4 * g;
     // survivor mask layout: pixel 0, 2 of the lane's four in bits 0, 1 and pixel 1, 3 in bits 16, 17
-    const int npx = g < gpr ? min(cw - x, 4) : 0;                          // pixels of the lane inside the cell
+    const int npx = lrow < rows_per_round ? min(cw - x, 4) : 0;            // pixels of the lane inside the cell
     const uint32_t colmask = (npx > 0 ? 1u : 0u) | (npx > 1 ? 1u << 16 : 0u) | (npx > 2 ? 2u : 0u) | (npx > 3 ? 2u << 16 : 0u);
 
     // cv::FAST(cell, T, nonmax) at T = iniThFAST; only if that returns nothing, at T = minThFAST (:808-815).  Pixels
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         const s16x2 thr1 = {(short)(T + 1), (short)(T + 1)};
         int nq = 0, nsq = 0;                            // wave-uniform queue fills
         for (int y0 = 0; y0 < ch; y0 += rows_per_round) {
-            const int y = y0 + (lane >> gsh);
+            const int y = y0 + lrow;
             uint32_t pm = 0;
             if (y < ch && colmask) {
                 const uint32_t* row = reinterpret_cast<const uint32_t*>(&tile[y * TS]) + g;   // tile row y = image row y-3
