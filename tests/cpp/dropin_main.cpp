@@ -3,6 +3,7 @@
 #include "../../visual-slam_amd/cpp/ORBextractor.h"
 #include "../../visual-slam_amd/cpp/ORBmatcher.h"
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <algorithm>
 
@@ -82,6 +83,18 @@ int main(int argc, char** argv)
     dump(f, uRight.data(), uRight.size() * sizeof(float));
     dump(f, depth.data(), depth.size() * sizeof(float));
     fclose(f);
+    {   // latency of operator() as the reference's per-frame callers see it (information only)
+        struct timespec t0, t1;
+        for (int rep = 0; rep < 2; ++rep) {
+            left.SetPyramidDownload(rep == 0);
+            left(imL, cv::Mat(), kL, dL);
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (int i = 0; i < 50; ++i) left(imL, cv::Mat(), kL, dL);
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            printf("operator() 752x480, 1200 features, pyramid download %s: %.0f us per call\n", rep == 0 ? "on" : "off",
+                   ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 50e3);
+        }
+    }
     printf("dropin ok: %zu / %zu keypoints, %d initial matches\n", k1.size(), k2.size(), nm);
     return 0;
 }

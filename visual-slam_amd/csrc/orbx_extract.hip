@@ -1161,6 +1161,14 @@ struct orbx_extractor {
     orbx_keypoint* d_okp = nullptr;
     uint8_t* d_odesc = nullptr;
     int32_t* d_ocount = nullptr;
+    uint8_t* h_img = nullptr;            // pinned host mirrors of the staging buffers
+    orbx_keypoint* h_okp = nullptr;
+    uint8_t* h_odesc = nullptr;
+    int32_t* h_ocount = nullptr;
+    hipGraphExec_t graph1 = nullptr;     // captured single-frame sequence of orbx_extract / orbx_extract_batch(n_frames = 1)
+    bool no_graph = false;
+    uint8_t* h_level = nullptr;          // pinned bounce buffer of orbx_pyramid_level
+    size_t h_level_bytes = 0;
     int key_total = 0;
     int max_border_threads = 0;
     int NCmax = 0;
@@ -1274,6 +1282,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK(hipMalloc(&ex->d_lvlkp, sizeof(uint32_t) * (size_t)geo.kp_total * B));
     HIP_CHECK(hipMalloc(&ex->d_lvlcnt, sizeof(int32_t) * geo.nlevels * B));
     for (auto& e : ex->ev) HIP_CHECK(hipEventCreate(&e));
+    ex->no_graph = getenv("ORBX_NO_GRAPH") != nullptr;
     *out = ex;
     return ORBX_OK;
 }
@@ -1286,7 +1295,10 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_cell_list, ex->d_rx, ex->d_ry, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
                     ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    void* hptrs[] = {ex->h_img, ex->h_okp, ex->h_odesc, ex->h_ocount, ex->h_level};
+    for (void* p : hptrs) if (p) (void)hipHostFree(p);
     for (auto& e : ex->ev) if (e) (void)hipEventDestroy(e);
+    if (ex->graph1) (void)hipGraphExecDestroy(ex->graph1);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
 }
@@ -1393,6 +1405,11 @@ static int ensure_staging(orbx_extractor* ex)
     HIP_CHECK(hipMalloc(&ex->d_okp, sizeof(orbx_keypoint) * (size_t)G.out_cap * B));
     HIP_CHECK(hipMalloc(&ex->d_odesc, (size_t)32 * G.out_cap * B));
     HIP_CHECK(hipMalloc(&ex->d_ocount, sizeof(int32_t) * B));
+    // pinned mirrors: pageable 2-D copies cost milliseconds per frame, pinned 1-D copies tens of microseconds
+    HIP_CHECK(hipHostMalloc(&ex->h_img, (size_t)G.width * G.height * B + 16, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&ex->h_okp, sizeof(orbx_keypoint) * (size_t)G.out_cap * B, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&ex->h_odesc, (size_t)32 * G.out_cap * B, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&ex->h_ocount, sizeof(int32_t) * B, hipHostMallocDefault));
     return ORBX_OK;
 }
 
@@ -1407,26 +1424,69 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_
     if (rc) return rc;
     const Geometry& G = ex->geo;
     const size_t fbytes = (size_t)G.width * G.height;
-    for (int f = 0; f < n_frames; ++f)
-        HIP_CHECK(hipMemcpy2DAsync(ex->d_img + f * fbytes, G.width, images + (ptrdiff_t)f * frame_stride, row_stride, G.width, G.height,
-                                   hipMemcpyHostToDevice, ex->stream));
-    rc = orbx_extract_batch_device(ex, ex->d_img, G.width, (ptrdiff_t)fbytes, n_frames, ex->d_okp, ex->d_odesc, ex->d_ocount, G.out_cap,
-                                   ex->stream);
-    if (rc) return rc;
-    HIP_CHECK(hipMemcpyAsync(counts, ex->d_ocount, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, ex->stream));
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
-    int status = ORBX_OK;
     for (int f = 0; f < n_frames; ++f) {
-        int n = counts[f];
-        if (n > cap_per_frame) { status = ORBX_ERR_CAPACITY; set_error("cap_per_frame smaller than the keypoint count"); n = cap_per_frame; }
-        if (n > 0) {
-            HIP_CHECK(hipMemcpyAsync(kps + (size_t)f * cap_per_frame, ex->d_okp + (size_t)f * G.out_cap, sizeof(orbx_keypoint) * n,
-                                     hipMemcpyDeviceToHost, ex->stream));
-            HIP_CHECK(hipMemcpyAsync(desc + (size_t)f * cap_per_frame * 32, ex->d_odesc + (size_t)f * G.out_cap * 32, (size_t)32 * n,
-                                     hipMemcpyDeviceToHost, ex->stream));
+        const uint8_t* src = images + (ptrdiff_t)f * frame_stride;
+        uint8_t* dst = ex->h_img + f * fbytes;
+        if (row_stride == G.width) std::memcpy(dst, src, fbytes);
+        else for (int y = 0; y < G.height; ++y) std::memcpy(dst + (size_t)y * G.width, src + (ptrdiff_t)y * row_stride, G.width);
+    }
+    // a few frames: one round trip (counts and whole output slots together); many frames: counts first, then what is used
+    const bool one_trip = n_frames <= 8;
+    auto enqueue = [&]() -> int {
+        HIP_CHECK(hipMemcpyAsync(ex->d_img, ex->h_img, fbytes * n_frames, hipMemcpyHostToDevice, ex->stream));
+        const int r = launch_frames(ex, ex->stream, 0, n_frames, ex->profiling, ex->d_img, G.width, (ptrdiff_t)fbytes, ex->d_okp, ex->d_odesc,
+                                    ex->d_ocount, G.out_cap);
+        if (r) return r;
+        HIP_CHECK(hipMemcpyAsync(ex->h_ocount, ex->d_ocount, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, ex->stream));
+        if (one_trip) {
+            HIP_CHECK(hipMemcpyAsync(ex->h_okp, ex->d_okp, sizeof(orbx_keypoint) * (size_t)G.out_cap * n_frames, hipMemcpyDeviceToHost, ex->stream));
+            HIP_CHECK(hipMemcpyAsync(ex->h_odesc, ex->d_odesc, (size_t)32 * G.out_cap * n_frames, hipMemcpyDeviceToHost, ex->stream));
         }
+        return ORBX_OK;
+    };
+    if (n_frames == 1 && !ex->profiling && !ex->no_graph) {
+        // the per-frame call of the reference's callers: the whole sequence (upload, 13 kernels, download) is captured once
+        // into a HIP graph and replayed, which removes most of the per-launch latency
+        if (!ex->graph1) {
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(ex->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue();
+            const hipError_t e = hipStreamEndCapture(ex->stream, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            HIP_CHECK(e);
+            const hipError_t ei = hipGraphInstantiate(&ex->graph1, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            HIP_CHECK(ei);
+        }
+        HIP_CHECK(hipGraphLaunch(ex->graph1, ex->stream));
+        ex->last_frames = 1;
+    } else {
+        rc = enqueue();
+        if (rc) return rc;
+        ex->last_frames = n_frames;
     }
     HIP_CHECK(hipStreamSynchronize(ex->stream));
+    if (!one_trip) {
+        for (int f = 0; f < n_frames; ++f) {
+            const int n = std::min(ex->h_ocount[f], G.out_cap);
+            if (n <= 0) continue;
+            HIP_CHECK(hipMemcpyAsync(ex->h_okp + (size_t)f * G.out_cap, ex->d_okp + (size_t)f * G.out_cap, sizeof(orbx_keypoint) * n,
+                                     hipMemcpyDeviceToHost, ex->stream));
+            HIP_CHECK(hipMemcpyAsync(ex->h_odesc + (size_t)f * G.out_cap * 32, ex->d_odesc + (size_t)f * G.out_cap * 32, (size_t)32 * n,
+                                     hipMemcpyDeviceToHost, ex->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(ex->stream));
+    }
+    int status = ORBX_OK;
+    for (int f = 0; f < n_frames; ++f) {
+        int n = ex->h_ocount[f];
+        counts[f] = n;
+        if (n > cap_per_frame) { status = ORBX_ERR_CAPACITY; set_error("cap_per_frame smaller than the keypoint count"); n = cap_per_frame; }
+        if (n > 0) {
+            std::memcpy(kps + (size_t)f * cap_per_frame, ex->h_okp + (size_t)f * G.out_cap, sizeof(orbx_keypoint) * n);
+            std::memcpy(desc + (size_t)f * cap_per_frame * 32, ex->h_odesc + (size_t)f * G.out_cap * 32, (size_t)32 * n);
+        }
+    }
     return status;
 }
 
@@ -1463,8 +1523,19 @@ int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, p
     hipLaunchKernelGGL(k_borders, dim3((ex->hlv[level].border_threads + 255) / 256), dim3(256), 0, ex->stream,
                        ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes, 0ull, ex->d_lv + level, kEdge, 8, 1 << 20);
     HIP_CHECK(hipStreamSynchronize(ex->stream));
-    const uint8_t* src = ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes + L.offset + (kRoiX - kEdge);
-    HIP_CHECK(hipMemcpy2D(dst, dst_stride, src, L.stride, L.w + 2 * kEdge, L.rows, hipMemcpyDeviceToHost));
+    // one contiguous copy of the padded level into a pinned buffer, then the rows to the caller (a pageable 2-D copy
+    // costs milliseconds)
+    const size_t bytes = (size_t)L.stride * L.rows;
+    if (ex->h_level_bytes < bytes) {
+        if (ex->h_level) (void)hipHostFree(ex->h_level);
+        ex->h_level = nullptr; ex->h_level_bytes = 0;
+        HIP_CHECK(hipHostMalloc(&ex->h_level, bytes, hipHostMallocDefault));
+        ex->h_level_bytes = bytes;
+    }
+    HIP_CHECK(hipMemcpyAsync(ex->h_level, ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes + L.offset, bytes, hipMemcpyDeviceToHost, ex->stream));
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    for (int y = 0; y < L.rows; ++y)
+        std::memcpy(dst + (size_t)y * dst_stride, ex->h_level + (size_t)y * L.stride + (kRoiX - kEdge), (size_t)L.w + 2 * kEdge);
     return ORBX_OK;
 }
 
