@@ -95,6 +95,15 @@ int main(int argc, char** argv)
                    ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 50e3);
         }
     }
+    {   // SearchForInitialization as Tracking::MonocularInitialization calls it (information only)
+        struct timespec t0, t1;
+        std::vector<int> mm;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int i = 0; i < 20; ++i) { std::vector<cv::Point2f> pv(prev); matcher.SearchForInitialization(F1, F2, pv, mm, 100); }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        printf("SearchForInitialization %zu x %zu features, window 100: %.0f us per call\n", k1.size(), k2.size(),
+               ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 20e3);
+    }
     printf("dropin ok: %zu / %zu keypoints, %d initial matches\n", k1.size(), k2.size(), nm);
     return 0;
 }

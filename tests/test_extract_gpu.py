@@ -20,6 +20,8 @@ CONFIGS = [
     (640, 480, 1000, 3, 2.0, 20, 7, 8),      # exact 2x decimation (INTER_AREA reroute)
     (3840, 2160, 8000, 12, 1.2, 20, 7, 9),   # 4K stress shape: quadtree keys in device memory, 1500-keypoint quotas
     (480, 640, 1000, 8, 1.2, 20, 7, 10),     # portrait
+    (1600, 1200, 3000, 8, 1.2, 20, 7, 11),   # between 1 and 2 Mpixel: 512-thread quadtree workgroups
+    (1241, 376, 2000, 8, 1.2, 12, 12, 12),   # KITTI04-12-like thresholds (ini == min), cells above 38 pixels in one level
 ]
 
 
