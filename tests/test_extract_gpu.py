@@ -142,7 +142,7 @@ def test_octree_standalone_random(vsa, oracle):
         if round(W / H) < 1:
             continue
         n = int(rng.integers(0, (40000 if it % 8 == 0 else 6000) if it % 4 == 0 else 500))
-        N = int(rng.integers(0, 400)) if it % 7 else 1500
+        N = int(rng.integers(0, 400)) if it % 7 else (1500 if it % 14 else 4000)   # 4000: node tables beyond LDS
         pts = set()
         cx, cy = int(rng.integers(3, W - 3)), int(rng.integers(3, H - 3))
         for _ in range(n):
@@ -161,3 +161,37 @@ def test_octree_standalone_random(vsa, oracle):
             got = vsa.distribute_octree(keys, 16, 16 + W, 16, 16 + H, N, device=0, key_storage=storage)
             assert len(got) == len(sel), (it, W, H, len(pts), N, storage)
             assert np.array_equal(got, keys[sel]), (it, W, H, len(pts), N, storage)
+
+
+def test_random_geometries(vsa, oracle):
+    """Seeded sweep over image sizes, pyramid shapes and thresholds: final keypoints and descriptors bit-exact, and the
+    configurations the oracle rejects (a level narrower than the reference can handle) rejected by the library too."""
+    rng = np.random.default_rng(2024)
+    ran = 0
+    for case in range(40):
+        w = int(rng.integers(96, 1000)); h = int(rng.integers(96, 800))
+        nf = int(rng.integers(50, 3000)); nl = int(rng.integers(1, 9))
+        sf = float(np.float32(rng.choice([1.1, 1.2, 1.25, 1.3, 1.5, 2.0])))
+        ini = int(rng.integers(5, 40)); mn = int(rng.integers(1, ini + 1))
+        mode = int(rng.integers(0, 2))
+        img = vsa.synth_frame(1000 + case, w, h)
+        op = oracle.make_params(nf, sf, nl, ini, mn, mode)
+        try:
+            okps, odesc = oracle.Extractor(op).extract(img, cap=nf + 64 * nl + 64)
+        except Exception:
+            okps = None
+        try:
+            ex = vsa.Extractor(vsa.make_params(nf, sf, nl, ini, mn, mode), w, h, max_batch=1, device=0)
+        except RuntimeError:
+            assert okps is None, f"case {case} ({w}x{h}, {nl} levels, scale {sf}): library rejects what the oracle accepts"
+            continue
+        assert okps is not None, f"case {case} ({w}x{h}, {nl} levels, scale {sf}): library accepts what the oracle rejects"
+        kps, desc = ex.extract(img)
+        ex.close()
+        tag = f"case {case}: {w}x{h} nf={nf} nl={nl} sf={sf} ini={ini} min={mn} mode={mode}"
+        assert len(kps) == len(okps), tag
+        for f in ("x", "y", "size", "angle", "response", "octave"):
+            assert np.array_equal(kps[f], okps[f]), f"{tag}: {f}"
+        assert np.array_equal(desc, odesc), tag
+        ran += 1
+    assert ran >= 20

@@ -569,15 +569,19 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
                                                         const uint16_t* __restrict__ cellcnt, int ncells,
                                                         uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int key_total,
                                                         uint32_t* __restrict__ lvlkp, int kp_total,
-                                                        int32_t* __restrict__ lvlcnt, int nlevels, int NCmax, int KL)
+                                                        int32_t* __restrict__ lvlcnt, int nlevels, int NCmax, int KL,
+                                                        unsigned char* __restrict__ gmem, unsigned long long gstride)
 {
-    extern __shared__ __align__(16) unsigned char ot_mem[];
+    extern __shared__ __align__(16) unsigned char ot_lds[];
     __shared__ int s_nk;
     const int tid = threadIdx.x;
     const int level = blockIdx.y, frame = blockIdx.x;
     const DevLevel& L = lv[level];
     OtShared s;
     const int NT = blockDim.x;
+    // the node tables live in LDS; a quota too large for it (thousands of keypoints in one level) takes a slice of device
+    // memory instead (gmem != nullptr, KL == 0): the waves of a workgroup share one CU's L1, so barriers order it the same way
+    unsigned char* ot_mem = gmem ? gmem + ((unsigned long long)frame * nlevels + level) * gstride : ot_lds;
     const size_t keyOff = ot_carve(s, ot_mem, NCmax, kOctThreads);
 
     const uint16_t* cnt = cellcnt + (unsigned long long)frame * ncells + L.cell_first;
@@ -627,10 +631,11 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
 __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int nk,
                                                                int W, int H, int nIni, float hX, int N,
                                                                uint32_t* __restrict__ out, int outCap, int32_t* __restrict__ nOut, int NC,
-                                                               int KL)
+                                                               int KL, unsigned char* __restrict__ gmem)
 {
-    extern __shared__ __align__(16) unsigned char ot_mem[];
+    extern __shared__ __align__(16) unsigned char ot_lds[];
     OtShared s;
+    unsigned char* ot_mem = gmem ? gmem : ot_lds;
     const size_t keyOff = ot_carve(s, ot_mem, NC, kOctThreads);
     const uint32_t* K = keys; uint16_t* NO = nodeOf;
     if (nk <= KL) {                     // KL == 0 keeps the keys in device memory
@@ -1175,6 +1180,8 @@ struct orbx_extractor {
     int KL = 0;              // keys of one level that fit the quadtree's LDS key arrays
     int oct_threads = 256;
     size_t oct_lds = 0;
+    unsigned char* d_octmem = nullptr;   // device-memory working set of the quadtree when it does not fit LDS
+    size_t oct_gstride = 0;
     int last_frames = 0;
     bool profiling = false;
 
@@ -1246,7 +1253,12 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         ex->oct_threads = px >= 2000000 ? 1024 : px >= 1000000 ? 512 : 256;
     }
     ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads, ex->KL);
-    if (ex->oct_lds > 150 * 1024) { delete ex; set_error("per-level keypoint quota too large for the quadtree working set in LDS"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+    if (ex->oct_lds > 150 * 1024) {          // node tables beyond LDS: per-workgroup slices of device memory, keys there too
+        ex->KL = 0;
+        ex->oct_gstride = (ot_lds_bytes(ex->NCmax, kOctThreads, 0) + 255) & ~(size_t)255;
+        ex->oct_lds = 64;
+        HIP_CHECK(hipMalloc(&ex->d_octmem, ex->oct_gstride * geo.nlevels * (size_t)max_batch));
+    }
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ex->oct_lds));
     HIP_CHECK(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
     const size_t B = (size_t)max_batch;
@@ -1292,7 +1304,7 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    void* ptrs[] = {ex->d_lv, ex->d_cells, ex->d_cell_list, ex->d_rx, ex->d_ry, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
+    void* ptrs[] = {ex->d_octmem, ex->d_lv, ex->d_cells, ex->d_cell_list, ex->d_rx, ex->d_ry, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
                     ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     void* hptrs[] = {ex->h_img, ex->h_okp, ex->h_odesc, ex->h_ocount, ex->h_level};
@@ -1363,7 +1375,9 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
         dim3 grid(B, G.nlevels);
         hipLaunchKernelGGL(k_octree, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, cand, G.cand_total,
                            cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp,
-                           G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL);
+                           G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL,
+                           ex->d_octmem ? ex->d_octmem + (size_t)f0 * G.nlevels * ex->oct_gstride : nullptr,
+                           (unsigned long long)ex->oct_gstride);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
     {
@@ -1674,19 +1688,21 @@ int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, in
     if (nIni <= 0 || nIni > kMaxRoots || W >= 4096 || H >= 4096) { set_error("orbx_distribute_octree: unsupported box"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     const float hX = (float)W / nIni;
     const int NC = std::max(std::max(N + 3, 4 * nIni) + 9, 64);
-    const int KL = key_storage == 0 ? 4096 : 0;
-    const size_t lds = ot_lds_bytes(NC, kOctThreads, KL);
-    if (lds > 150 * 1024) { set_error("N too large for the quadtree working set in LDS"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+    int KL = key_storage == 0 ? 4096 : 0;
+    size_t lds = ot_lds_bytes(NC, kOctThreads, KL);
+    const bool in_device_memory = lds > 150 * 1024;       // node tables beyond LDS
+    if (in_device_memory) { KL = 0; lds = 64; }
     int rc = select_device(device);
     if (rc) return rc;
-    uint32_t *d_keys = nullptr, *d_out = nullptr; uint16_t* d_no = nullptr; int32_t* d_n = nullptr;
+    uint32_t *d_keys = nullptr, *d_out = nullptr; uint16_t* d_no = nullptr; int32_t* d_n = nullptr; unsigned char* d_mem = nullptr;
+    if (in_device_memory) HIP_CHECK(hipMalloc(&d_mem, ot_lds_bytes(NC, kOctThreads, 0)));
     HIP_CHECK(hipMalloc(&d_keys, sizeof(uint32_t) * std::max(n, 1)));
     HIP_CHECK(hipMalloc(&d_no, sizeof(uint16_t) * std::max(n, 1)));
     HIP_CHECK(hipMalloc(&d_out, sizeof(uint32_t) * NC));
     HIP_CHECK(hipMalloc(&d_n, sizeof(int32_t)));
     if (n) HIP_CHECK(hipMemcpy(d_keys, packed_keys, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree_single), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(256), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL);
+    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(256), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL, d_mem);
     HIP_CHECK(hipGetLastError());
     int32_t cnt = 0;
     HIP_CHECK(hipMemcpy(&cnt, d_n, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1694,7 +1710,7 @@ int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, in
     int status = ORBX_OK;
     if (cnt > cap) { status = ORBX_ERR_CAPACITY; cnt = cap; }
     if (cnt > 0) HIP_CHECK(hipMemcpy(out, d_out, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
-    (void)hipFree(d_keys); (void)hipFree(d_no); (void)hipFree(d_out); (void)hipFree(d_n);
+    (void)hipFree(d_keys); (void)hipFree(d_no); (void)hipFree(d_out); (void)hipFree(d_n); (void)hipFree(d_mem);
     return status;
 }
 
