@@ -255,12 +255,6 @@ int orbx_stereo_match_batch_device(orbx_matcher* m,
                                    const float* scale_factors, int nlevels, int n_rows, float min_d, float max_d,
                                    int32_t* d_best_dist, int32_t* d_best_idx, void* stream);
 
-/* ------------------------------------------------------------------------------------------ */
-/* Synthetic inputs for benchmarks and tests (no counterpart in the reference)                 */
-/* ------------------------------------------------------------------------------------------ */
-/* Frame generator: PCG32 seeded 0x5EED0000 + frame_index; W*H/200 random rectangles (side 6..48,
- * intensity 16..240) painted in order over mid-grey, then uniform noise in [-6,6]. */
-void orbx_synth_frame(uint32_t frame_index, int w, int h, uint8_t* out, ptrdiff_t stride);
 /* Frame::ComputeStereoMatches, sub-pixel part (src/Frame.cc:551-639), on the pyramids that `left` and `right` hold
  * for frames 0..n_pairs-1 of their last batches (the pair's two images, extracted with identical settings): for every
  * left keypoint whose Hamming match is below (TH_HIGH+TH_LOW)/2 the 11x11 SAD search over +-5 columns at the
@@ -279,12 +273,65 @@ int orbx_stereo_refine(orbx_extractor* left, orbx_extractor* right,
                        const int32_t* best_dist, const int32_t* best_idx, float bf, float min_d, float max_d,
                        float* uright, float* depth);
 
+/* ------------------------------------------------------------------------------------------ */
+/* The Hamming consumers that follow extraction                                                */
+/* ------------------------------------------------------------------------------------------ */
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:483-548), the selection at :513-542, for a batch of map
+ * points: group g holds the descriptors desc[group_ptr[g] .. group_ptr[g+1]) (the rows of the key frames that observe
+ * the point, in the order of mObservations); best[g] = index inside the group of the descriptor with the least median
+ * distance to the group (median = element (n-1)/2 of the sorted row that includes the zero distance to itself, :535;
+ * the first index wins ties), -1 for an empty group (the reference returns early, :510-511). */
+int orbx_distinctive_descriptors(orbx_matcher* m, const uint8_t* desc, const int32_t* group_ptr, int n_groups, int32_t* best);
+/* Device-resident form; asynchronous on `stream`. */
+int orbx_distinctive_descriptors_device(orbx_matcher* m, const uint8_t* d_desc, const int32_t* d_group_ptr, int n_groups,
+                                        int64_t n_rows, int32_t* d_best, void* stream);
+
+/* A DBoW2 vocabulary tree (ORBVocabulary, include/ORBVocabulary.h:52-53 = TemplatedVocabulary<FORB::TDescriptor, FORB>)
+ * on plain arrays, as TemplatedVocabulary::loadFromTextFile reads it (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:
+ * 1351-1437): node 0 is the root (its entries are ignored), node i >= 1 has parent[i] < i, a leaf flag, a 32-byte
+ * descriptor and a weight; children keep node order and words number the leaves in node order.  scoring / weighting are
+ * the ScoringType / WeightingType values of BowVector.h:36-53 (L1_NORM 0 .. DOT_PRODUCT 5; TF_IDF 0, TF 1, IDF 2,
+ * BINARY 3).  The arrays are copied; the tree lives in device memory until destroy. */
+typedef struct orbx_vocabulary orbx_vocabulary;
+int orbx_vocabulary_create(int device, int k, int L, int scoring, int weighting, int n_nodes,
+                           const int32_t* parent, const uint8_t* is_leaf, const uint8_t* descriptors, const double* weight,
+                           orbx_vocabulary** out);
+void orbx_vocabulary_destroy(orbx_vocabulary* v);
+/* number of words (TemplatedVocabulary::size) */
+int orbx_vocabulary_words(const orbx_vocabulary* v);
+/* TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (:1230-1272) for n features: the descent
+ * by least FORB::distance (first child wins ties).  d_word[i] = word id, d_node[i] = the node passed at level
+ * L - levelsup (0 = root when that level is <= 0; the reference leaves it unset when the descent reaches a leaf above
+ * that level: here it is then that leaf).  d_counts != NULL: the features are n_frames blocks of cap_per_frame rows of
+ * which the first d_counts[f] are valid (the layout orbx_extract_batch_device leaves); other rows get -1.  With
+ * d_counts == NULL all n_frames * cap_per_frame rows are features.  Asynchronous on `stream`. */
+int orbx_vocabulary_descend_device(orbx_vocabulary* v, const uint8_t* d_desc, const int32_t* d_counts, int cap_per_frame,
+                                   int n_frames, int levelsup, int32_t* d_word, int32_t* d_node, void* stream);
+/* TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) (:1139-1207) as Frame::ComputeBoW and
+ * KeyFrame::ComputeBoW call it (src/Frame.cc:395-402, levelsup 4): the descent on the device, then the BowVector
+ * (addWeight / addIfNotExist by weighting type, normalisation by scoring type, BowVector.cpp:34-84; doubles, summed in
+ * feature order) and the FeatureVector on the host.  bow_ids / bow_values (capacity n) come back ascending by word id;
+ * fv_node_ids (capacity n), fv_node_ptr (n+1), fv_features (n) in the orbx_feature_vector layout. */
+int orbx_vocabulary_transform(orbx_vocabulary* v, const uint8_t* desc, int n, int levelsup,
+                              uint32_t* bow_ids, double* bow_values, int32_t* n_words,
+                              uint32_t* fv_node_ids, int32_t* fv_node_ptr, int32_t* fv_features, int32_t* fv_n_nodes);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Synthetic inputs for benchmarks and tests (no counterpart in the reference)                 */
+/* ------------------------------------------------------------------------------------------ */
+/* Frame generator: PCG32 seeded 0x5EED0000 + frame_index; W*H/200 random rectangles (side 6..48,
+ * intensity 16..240) painted in order over mid-grey, then uniform noise in [-6,6]. */
+void orbx_synth_frame(uint32_t frame_index, int w, int h, uint8_t* out, ptrdiff_t stride);
 /* Stereo pair: the right image paints every rectangle shifted left by its own disparity 0..40. */
 void orbx_synth_stereo(uint32_t frame_index, int w, int h, uint8_t* left, uint8_t* right, ptrdiff_t stride);
 /* n iid uniform 256-bit descriptors from PCG32(seed). */
 void orbx_synth_descriptors(uint32_t seed, int64_t n, uint8_t* out);
 /* nq queries: map rows picked by PCG32(seed) with Binomial(256, 0.08) bit flips; src_idx receives the rows. */
 void orbx_synth_queries(uint32_t seed, const uint8_t* map, int64_t n_map, int nq, uint8_t* out, int64_t* src_idx);
+/* A synthetic vocabulary: the full k-ary tree of depth L in breadth-first numbering; a node's descriptor is its
+ * parent's with PCG32(seed) bit flips (fewer with depth), leaves weigh 0.5 + (word id % 7).  Returns the node count
+ * (k^(L+1)-1)/(k-1), the capacity the four arrays need; with parent == NULL only that count; -1 for bad k / L. */
+int orbx_synth_vocabulary(uint32_t seed, int k, int L, int32_t* parent, uint8_t* is_leaf, uint8_t* descriptors, double* weight);
 
 #ifdef __cplusplus
 }

@@ -155,6 +155,30 @@ void  orc_stereo_refine(const orc_extractor* left, const orc_extractor* right,
                         const int32_t* best_dist, const int32_t* best_idx,
                         float bf, float min_d, float max_d, float* uright, float* depth, int32_t* sad);
 
+/* MapPoint::ComputeDistinctiveDescriptors selection, src/MapPoint.cc:513-547: of the n descriptors of one map point, the
+ * index of the one with the least median Hamming distance to the set (median = sorted row [(int)(0.5*(n-1))], the
+ * row including the zero distance to itself; first index wins ties).  -1 for n == 0. */
+int   orc_distinctive_descriptor(const uint8_t* desc, int n);
+
+/* DBoW2 vocabulary tree on plain arrays (what TemplatedVocabulary::loadFromTextFile reads, Thirdparty/DBoW2/DBoW2/
+ * TemplatedVocabulary.h:1351-1437): node 0 is the root; node i >= 1 has parent[i] < i, a leaf flag, a 32-byte descriptor
+ * and a weight.  Children keep node order; word ids number the leaves in node order. */
+typedef struct orc_vocabulary {
+    int32_t k, L, scoring, weighting;     /* ScoringType / WeightingType values of BowVector.h:36-53 */
+    int32_t n_nodes;
+    const int32_t* parent; const uint8_t* is_leaf; const uint8_t* descriptors; const double* weight;
+} orc_vocabulary;
+
+/* TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup), TemplatedVocabulary.h:1139-1207 with the
+ * single-feature descent :1230-1272 and BowVector::addWeight/addIfNotExist/normalize (BowVector.cpp:34-84).
+ * Per feature: word[i] and node[i] (the node at level L-levelsup; the reference leaves it unset when the descent ends
+ * above that level, here it is then the leaf reached).  bow_ids/bow_values (capacity n) ascending by word id;
+ * fv_* as orc_feature_vector (capacities n, n+1, n).  Returns 0, or -1 for a malformed tree. */
+int   orc_vocabulary_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup,
+                               int32_t* word, int32_t* node,
+                               uint32_t* bow_ids, double* bow_values, int32_t* n_words,
+                               uint32_t* fv_node_ids, int32_t* fv_node_ptr, int32_t* fv_features, int32_t* fv_n_nodes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ class Params(C.Structure):
 
 
 def _build_if_needed():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("orb_oracle_extract.c", "orb_oracle_match.c", "orb_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("orb_oracle_extract.c", "orb_oracle_match.c", "orb_oracle_bow.c", "orb_oracle.h")]
     if not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
@@ -346,3 +346,37 @@ def stereo_match(kl, dl, kr, dr, scale_factors, n_rows, min_d, max_d):
     bd = np.zeros(len(kl), np.int32); bi = np.zeros(len(kl), np.int32)
     lib.orc_stereo_match(_ptr(kl), _ptr(dl), len(kl), _ptr(kr), _ptr(dr), len(kr), _ptr(sf), len(sf), n_rows, min_d, max_d, _ptr(bd), _ptr(bi))
     return bd, bi
+
+
+class VocabularyC(C.Structure):
+    _fields_ = [("k", C.c_int32), ("L", C.c_int32), ("scoring", C.c_int32), ("weighting", C.c_int32), ("n_nodes", C.c_int32),
+                ("parent", _vp), ("is_leaf", _vp), ("descriptors", _vp), ("weight", _vp)]
+
+
+lib.orc_distinctive_descriptor.restype = _i; lib.orc_distinctive_descriptor.argtypes = [_vp, _i]
+lib.orc_vocabulary_transform.restype = _i
+lib.orc_vocabulary_transform.argtypes = [C.POINTER(VocabularyC), _vp, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp,
+                                         C.POINTER(C.c_int32)]
+
+
+def distinctive_descriptor(desc):
+    desc = np.ascontiguousarray(desc, np.uint8)
+    return lib.orc_distinctive_descriptor(_ptr(desc) if len(desc) else None, len(desc))
+
+
+def vocabulary_transform(k, L, parent, is_leaf, descriptors, weight, desc, levelsup=4, scoring=0, weighting=0):
+    """Returns (word, node, bow_ids, bow_values, fv_node_ids, fv_node_ptr, fv_features)."""
+    parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+    descriptors = np.ascontiguousarray(descriptors, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = desc.shape[0]
+    voc = VocabularyC(k, L, scoring, weighting, len(parent), _ptr(parent), _ptr(is_leaf), _ptr(descriptors), _ptr(weight))
+    word = np.zeros(max(n, 1), np.int32); node = np.zeros(max(n, 1), np.int32)
+    ids = np.zeros(max(n, 1), np.uint32); vals = np.zeros(max(n, 1), np.float64)
+    fn = np.zeros(max(n, 1), np.uint32); fp = np.zeros(n + 1, np.int32); ff = np.zeros(max(n, 1), np.int32)
+    nw = C.c_int32(0); nn = C.c_int32(0)
+    rc = lib.orc_vocabulary_transform(C.byref(voc), _ptr(desc), n, levelsup, _ptr(word), _ptr(node), _ptr(ids), _ptr(vals), C.byref(nw),
+                                      _ptr(fn), _ptr(fp), _ptr(ff), C.byref(nn))
+    if rc:
+        raise ValueError("malformed vocabulary tree")
+    return word[:n], node[:n], ids[:nw.value], vals[:nw.value], fn[:nn.value], fp[:nn.value + 1], ff[:fp[nn.value]]

@@ -31,7 +31,15 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
     bow_f = np.frombuffer(raw, np.int32, n2, off); off += n2 * 4
     nL, nR = np.frombuffer(raw, np.int32, 2, off); off += 8
     u_right = np.frombuffer(raw, np.float32, nL, off); off += nL * 4
-    depth = np.frombuffer(raw, np.float32, nL, off)
+    depth = np.frombuffer(raw, np.float32, nL, off); off += nL * 4
+    nbw, nfv = np.frombuffer(raw, np.int32, 2, off); off += 8
+    bow = np.frombuffer(raw, np.dtype([("id", "<u4"), ("v", "<f8")]), nbw, off); off += nbw * 12
+    fv_nodes, fv_lists = [], []
+    for _ in range(nfv):
+        nid, cnt = np.frombuffer(raw, np.uint32, 2, off); off += 8
+        fv_nodes.append(int(nid)); fv_lists.append(np.frombuffer(raw, np.uint32, int(cnt), off)); off += int(cnt) * 4
+    self_score, cross_score = np.frombuffer(raw, np.float64, 2, off); off += 16
+    nobs, best_obs = np.frombuffer(raw, np.int32, 2, off)
 
     w, h = 640, 480
     im1 = vsa.synth_frame(12, w, h)
@@ -70,3 +78,16 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
     our, odp, _ = oracle.stereo_refine(oexl, oexr, kl, kr, o[0], o[1], float(bf), 0.0, max_d)
     assert np.count_nonzero(our >= 0) > 50
     assert np.array_equal(u_right, our) and np.array_equal(depth, odp)
+
+    # Frame::ComputeBoW through ORBVocabulary (text file -> loadFromTextFile -> transform(..., 4))
+    parent, leaf, vdesc, weight = vsa.synth_vocabulary(9, 10, 5)
+    _, _, oids, ovals, ofn, ofp, off_ = oracle.vocabulary_transform(10, 5, parent, leaf, vdesc, weight, od1, 4)
+    assert np.array_equal(bow["id"], oids) and np.array_equal(bow["v"], ovals) and len(oids) > 100
+    assert fv_nodes == list(ofn)
+    for k, lst in enumerate(fv_lists):
+        assert np.array_equal(lst, off_[ofp[k]:ofp[k + 1]])
+    assert abs(self_score - 1.0) < 1e-12 and 0.0 <= cross_score < 1.0
+
+    # MapPoint::ComputeDistinctiveDescriptors through ORBmatcher::DistinctiveDescriptor
+    obs = od1[[i * 7 % len(od1) for i in range(nobs)]]
+    assert nobs == 9 and best_obs == oracle.distinctive_descriptor(obs)

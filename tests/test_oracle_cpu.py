@@ -213,3 +213,50 @@ def test_extract_is_deterministic_and_bounded(oracle, vsa):
     assert (k1["angle"] >= 0).all() and (k1["angle"] <= 360).all()
     kc, dc = ex.extract(np.full((480, 640), 128, np.uint8))
     assert len(kc) == 0
+
+
+def test_distinctive_descriptor_known_answers(oracle):
+    """src/MapPoint.cc:513-547 by hand: descriptors with 0, 1, 2, 3 and 40 set bits.  Rows of the distance matrix sorted:
+    [0,1,2,3,40] [0,1,1,2,39] [0,1,1,2,38] [0,1,2,3,37] [0,37,38,39,40]; medians (element 2): 2, 1, 1, 2, 38 -> index 1
+    (the first of the two rows with median 1)."""
+    d = np.zeros((5, 32), np.uint8)
+    d[1, 0] = 0x01; d[2, 0] = 0x03; d[3, 0] = 0x07; d[4, :5] = 0xFF
+    assert oracle.distinctive_descriptor(d) == 1
+    assert oracle.distinctive_descriptor(d[:1]) == 0
+    assert oracle.distinctive_descriptor(d[:2]) == 0          # n = 2: the median is the zero on the diagonal for both rows
+    assert oracle.distinctive_descriptor(d[:0]) == -1
+    # n = 4: element (int)(0.5*3) = 1 of each sorted row = the distance to the nearest other descriptor
+    assert oracle.distinctive_descriptor(d[[4, 0, 3, 1]]) == 1   # rows: [0,37,39,40] [0,1,3,40] [0,2,3,37] [0,1,2,39] -> medians 37,1,2,1
+
+
+def test_vocabulary_transform_known_answers(oracle):
+    """A two-level tree written by hand (TemplatedVocabulary.h:1230-1272): root -> A (all zero bits), B (all one bits);
+    A -> words 0 (zero), 1 (low byte set); B is itself word 2.  L = 2."""
+    parent = np.array([-1, 0, 0, 1, 1], np.int32)
+    leaf = np.array([0, 0, 1, 1, 1], np.uint8)
+    desc = np.zeros((5, 32), np.uint8); desc[2] = 0xFF; desc[4, 0] = 0xFF
+    weight = np.array([0, 0, 2.0, 1.0, 0.5])
+    feats = np.zeros((5, 32), np.uint8)
+    feats[1] = 0xFF                       # -> B (word 2)
+    feats[2, 0] = 0xFF                    # -> A -> word 1
+    feats[3, 0] = 0x0F                    # 4 bits from either child of A: the first (word 0) wins the tie
+    feats[4, :16] = 0xFF                  # 128 bits from A and from B: A wins the tie, then node 4 (120 vs 128)
+    word, node, ids, vals, fn, fp, ff = oracle.vocabulary_transform(2, 2, parent, leaf, desc, weight, feats, levelsup=1, scoring=0, weighting=0)
+    # word ids number the leaves in node order: node 2 (B) = word 0, node 3 = word 1, node 4 = word 2
+    assert list(word) == [1, 0, 2, 1, 2]
+    assert list(node) == [1, 2, 1, 1, 1]  # level L - levelsup = 1: A (1) or B (2, also the leaf reached)
+    assert list(ids) == [0, 1, 2]
+    # TF_IDF sums then L1: word 0 -> 2.0, word 1 -> 1+1, word 2 -> 0.5+0.5; norm 5
+    assert np.array_equal(vals, np.array([2.0, 2.0, 1.0]) / 5.0)
+    assert list(fn) == [1, 2] and list(fp) == [0, 4, 5] and list(ff) == [0, 2, 3, 4, 1]
+    # BINARY weighting (3): first weight only; DOT_PRODUCT scoring (5) with TF (1): divided by the number of words
+    vals_b = oracle.vocabulary_transform(2, 2, parent, leaf, desc, weight, feats, 1, 0, 3)[3]
+    assert np.array_equal(vals_b, np.array([2.0, 1.0, 0.5]) / 3.5)
+    vals_d = oracle.vocabulary_transform(2, 2, parent, leaf, desc, weight, feats, 1, 5, 1)[3]
+    assert np.array_equal(vals_d, np.array([2.0, 2.0, 1.0]) / 3.0)
+    # levelsup >= L: every feature files under the root
+    assert list(oracle.vocabulary_transform(2, 2, parent, leaf, desc, weight, feats, 2)[1]) == [0] * 5
+    # a stopped word (weight 0) leaves both vectors
+    w0 = weight.copy(); w0[4] = 0.0
+    r = oracle.vocabulary_transform(2, 2, parent, leaf, desc, w0, feats, 1)
+    assert list(r[2]) == [0, 1] and list(r[6]) == [0, 3, 1]

@@ -93,6 +93,14 @@ _SIGS = {
     "orbx_search_by_projection_lastframe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, C.POINTER(_i)]),
     "orbx_stereo_match": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _f, _f, _vp, _vp]),
     "orbx_stereo_match_batch_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "orbx_distinctive_descriptors": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "orbx_distinctive_descriptors_device": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "orbx_vocabulary_create": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "orbx_vocabulary_destroy": (None, [_vp]),
+    "orbx_vocabulary_words": (_i, [_vp]),
+    "orbx_vocabulary_descend_device": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "orbx_vocabulary_transform": (_i, [_vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, C.POINTER(C.c_int32)]),
+    "orbx_synth_vocabulary": (_i, [C.c_uint32, _i, _i, _vp, _vp, _vp, _vp]),
     "orbx_synth_frame": (None, [C.c_uint32, _i, _i, _vp, _pd]),
     "orbx_synth_stereo": (None, [C.c_uint32, _i, _i, _vp, _vp, _pd]),
     "orbx_synth_descriptors": (None, [C.c_uint32, _i64, _vp]),
@@ -345,6 +353,15 @@ class Matcher:
         _check(lib.orbx_hamming_csr(self.h, _ptr(q), q.shape[0], _ptr(t), t.shape[0], _ptr(rowptr), _ptr(cand), _ptr(dist)))
         return dist
 
+    def distinctive_descriptors(self, desc, group_ptr):
+        desc = np.ascontiguousarray(desc, np.uint8); group_ptr = np.ascontiguousarray(group_ptr, np.int32)
+        best = np.zeros(len(group_ptr) - 1, np.int32)
+        _check(lib.orbx_distinctive_descriptors(self.h, _ptr(desc) if len(desc) else None, _ptr(group_ptr), len(best), _ptr(best)))
+        return best
+
+    def distinctive_descriptors_device(self, d_desc, d_group_ptr, n_groups, n_rows, d_best, stream=None):
+        _check(lib.orbx_distinctive_descriptors_device(self.h, d_desc, d_group_ptr, n_groups, n_rows, d_best, stream))
+
     def search_for_initialization(self, k1, d1, k2, d2, bounds, prev_matched, window=100, nnratio=0.9, check_ori=True):
         k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
         d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
@@ -440,6 +457,52 @@ class Matcher:
         sf = np.ascontiguousarray(scale_factors, np.float32)
         _check(lib.orbx_stereo_match_batch_device(self.h, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, n_pairs, _ptr(sf), len(sf), n_rows,
                                                   min_d, max_d, d_best_dist, d_best_idx, stream))
+
+
+def synth_vocabulary(seed, k, L):
+    """orbx_synth_vocabulary: (parent, is_leaf, descriptors, weight) of a full k-ary tree of depth L."""
+    n = lib.orbx_synth_vocabulary(seed, k, L, None, None, None, None)
+    if n < 0:
+        raise ValueError("bad k / L")
+    parent = np.zeros(n, np.int32); leaf = np.zeros(n, np.uint8); desc = np.zeros((n, 32), np.uint8); weight = np.zeros(n, np.float64)
+    lib.orbx_synth_vocabulary(seed, k, L, _ptr(parent), _ptr(leaf), _ptr(desc), _ptr(weight))
+    return parent, leaf, desc, weight
+
+
+class Vocabulary:
+    """orbx_vocabulary: a DBoW2 tree in device memory (scoring / weighting: the enum values of DBoW2's BowVector.h)."""
+
+    def __init__(self, k, L, parent, is_leaf, descriptors, weight, scoring=0, weighting=0, device=-1):
+        parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        descriptors = np.ascontiguousarray(descriptors, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
+        h = C.c_void_p()
+        _check(lib.orbx_vocabulary_create(device, k, L, scoring, weighting, len(parent), _ptr(parent), _ptr(is_leaf), _ptr(descriptors),
+                                          _ptr(weight), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib.orbx_vocabulary_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def words(self):
+        return lib.orbx_vocabulary_words(self.h)
+
+    def descend_device(self, d_desc, d_counts, cap, n_frames, levelsup, d_word, d_node, stream=None):
+        _check(lib.orbx_vocabulary_descend_device(self.h, d_desc, d_counts, cap, n_frames, levelsup, d_word, d_node, stream))
+
+    def transform(self, desc, levelsup=4):
+        """Returns (bow_ids, bow_values, fv_node_ids, fv_node_ptr, fv_features)."""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = desc.shape[0]
+        ids = np.zeros(max(n, 1), np.uint32); vals = np.zeros(max(n, 1), np.float64)
+        fn = np.zeros(max(n, 1), np.uint32); fp = np.zeros(n + 1, np.int32); ff = np.zeros(max(n, 1), np.int32)
+        nw = C.c_int32(0); nn = C.c_int32(0)
+        _check(lib.orbx_vocabulary_transform(self.h, _ptr(desc) if n else None, n, levelsup, _ptr(ids), _ptr(vals), C.byref(nw),
+                                             _ptr(fn), _ptr(fp), _ptr(ff), C.byref(nn)))
+        return ids[:nw.value], vals[:nw.value], fn[:nn.value], fp[:nn.value + 1], ff[:fp[nn.value]]
 
 
 class FrameGrid:

@@ -49,6 +49,25 @@ int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b)
     return orbx_descriptor_distance(a.ptr(), b.ptr());
 }
 
+int ORBmatcher::DistinctiveDescriptor(const std::vector<cv::Mat>& vDescriptors)
+{
+    if (vDescriptors.empty()) return -1;
+    std::vector<unsigned char> rows(vDescriptors.size() * 32);
+    for (size_t i = 0; i < vDescriptors.size(); ++i) std::memcpy(&rows[i * 32], vDescriptors[i].ptr(), 32);
+    const int32_t ptr[2] = {0, (int32_t)vDescriptors.size()};
+    int32_t best = -1;
+    check(orbx_distinctive_descriptors(Context(), rows.data(), ptr, 1, &best), "DistinctiveDescriptor");
+    return best;
+}
+
+void ORBmatcher::DistinctiveDescriptors(const cv::Mat& descriptorRows, const std::vector<int>& vGroupPtr, std::vector<int>& vBestIdx)
+{
+    vBestIdx.assign(vGroupPtr.empty() ? 0 : vGroupPtr.size() - 1, -1);
+    if (vBestIdx.empty()) return;
+    const std::vector<unsigned char> rows = packed_rows(descriptorRows);
+    check(orbx_distinctive_descriptors(Context(), rows.data(), vGroupPtr.data(), (int)vBestIdx.size(), vBestIdx.data()), "DistinctiveDescriptors");
+}
+
 void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3)
 {
     std::vector<int32_t> sizes(L);

@@ -103,6 +103,13 @@ public:
                               const std::vector<cv::KeyPoint>& vKeysRight, const cv::Mat& descRight,
                               float bf, float b, std::vector<float>& vuRight, std::vector<float>& vDepth);
 
+    // MapPoint::ComputeDistinctiveDescriptors, the selection at src/MapPoint.cc:513-542: index (BestIdx) of the descriptor
+    // with the least median distance to the others; vDescriptors as the reference collects it (:500-508).  -1 if empty.
+    int DistinctiveDescriptor(const std::vector<cv::Mat>& vDescriptors);
+    // The same for many map points at once (local mapping after a key frame, or the whole map after a loop closure):
+    // descriptor rows of all points back to back, point g owning rows vGroupPtr[g] .. vGroupPtr[g+1]).
+    void DistinctiveDescriptors(const cv::Mat& descriptorRows, const std::vector<int>& vGroupPtr, std::vector<int>& vBestIdx);
+
     static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
 
     static const int TH_LOW;

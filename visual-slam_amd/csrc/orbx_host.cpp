@@ -493,4 +493,40 @@ void orbx_synth_queries(uint32_t seed, const uint8_t* map, int64_t n_map, int nq
     }
 }
 
+int orbx_synth_vocabulary(uint32_t seed, int k, int L, int32_t* parent, uint8_t* is_leaf, uint8_t* descriptors, double* weight)
+{
+    if (k < 2 || k > 20 || L < 1 || L > 10) return -1;
+    long long n = 1, level_nodes = 1;
+    for (int l = 1; l <= L; ++l) { level_nodes *= k; n += level_nodes; if (n > 0x7FFFFFFF) return -1; }
+    if (!parent) return (int)n;                                  // size query
+    Pcg32 rng(seed);
+    // breadth-first numbering: the children of node p are nodes p*k+1 .. p*k+k; a child's descriptor is its parent's
+    // with a share of bits flipped that shrinks with depth, so the descent has a meaningful nearest child
+    parent[0] = -1; is_leaf[0] = 0; weight[0] = 0; std::memset(descriptors, 0, 32);
+    long long first_of_level = 1; level_nodes = 1;
+    int words = 0;
+    for (int l = 1; l <= L; ++l) {
+        level_nodes *= k;
+        for (long long i = first_of_level; i < first_of_level + level_nodes; ++i) {
+            const long long p = (i - 1) / k;
+            parent[i] = (int32_t)p;
+            is_leaf[i] = l == L;
+            weight[i] = l == L ? 0.5 + (double)(words++ % 7) : 0.0;
+            for (int wd = 0; wd < 8; ++wd) {
+                uint32_t v;
+                if (l == 1) v = rng.next();
+                else {
+                    uint32_t flip = rng.next() & rng.next() & rng.next();
+                    for (int e = 2; e < std::min(l, 4); ++e) flip &= rng.next();
+                    std::memcpy(&v, descriptors + (size_t)p * 32 + wd * 4, 4);
+                    v ^= flip;
+                }
+                std::memcpy(descriptors + (size_t)i * 32 + wd * 4, &v, 4);
+            }
+        }
+        first_of_level += level_nodes;
+    }
+    return (int)n;
+}
+
 } // extern "C"

@@ -106,4 +106,9 @@ struct FrameGrid {
 int csr_distances(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
                   const int32_t* rowptr, const int32_t* cand, int32_t* dist_out);
 
+// device, private stream and growable device staging buffers (slot 0..7) of a matcher context (orbx_match.hip)
+int matcher_device(const orbx_matcher* m);
+void* matcher_stream(const orbx_matcher* m);
+int matcher_stage(orbx_matcher* m, int slot, size_t bytes, void** out);
+
 } // namespace orbx

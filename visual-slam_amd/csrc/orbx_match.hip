@@ -425,4 +425,13 @@ int csr_distances(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, i
 {
     return orbx_hamming_csr(m, q, nq, t, nt, rowptr, cand, dist_out);
 }
+int matcher_device(const orbx_matcher* m) { return m->device; }
+void* matcher_stream(const orbx_matcher* m) { return m->stream; }
+int matcher_stage(orbx_matcher* m, int slot, size_t bytes, void** out)
+{
+    if (slot < 0 || slot >= 8) return ORBX_ERR_BAD_ARG;
+    const int rc = reserve(&m->stage[slot], &m->stage_bytes[slot], bytes);
+    *out = m->stage[slot];
+    return rc;
+}
 }
