@@ -77,6 +77,15 @@ int orbx_level_size(const orbx_params* p, int width, int height, int level, int*
 /* Upper bound of keypoints one frame can return (quota + 3 per level: the quadtree can overshoot). */
 int orbx_keypoint_capacity(const orbx_params* p, int width, int height);
 
+/* Layout of the images the extract calls take.  The reference converts colour input to grey on the host before
+ * extraction (Tracking::GrabImageMonocular / GrabImageStereo / GrabImageRGBD, src/Tracking.cc:254-267 and the two
+ * sibling blocks: cvtColor with CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY by channel count and mbRGB);
+ * here the first pyramid kernel does it while it reads the frame: grey = (4899 R + 9617 G + 1868 B + 8192) >> 14, the
+ * 8-bit arithmetic of cv::cvtColor.  Default ORBX_INPUT_GRAY.  With a colour format, row_stride and frame_stride of the
+ * extract calls stay in bytes and a row holds width * channels bytes.  Call between extract calls, not during one. */
+enum { ORBX_INPUT_GRAY = 0, ORBX_INPUT_RGB = 1, ORBX_INPUT_BGR = 2, ORBX_INPUT_RGBA = 3, ORBX_INPUT_BGRA = 4 };
+int orbx_extractor_set_input_format(orbx_extractor* ex, int format);
+
 /* ORBextractor::operator() for one host image.  kps/desc sized cap (desc: cap x 32 bytes). */
 int orbx_extract(orbx_extractor* ex, const uint8_t* image, ptrdiff_t stride,
                  orbx_keypoint* kps, uint8_t* desc, int cap, int* n);

@@ -155,6 +155,12 @@ void  orc_stereo_refine(const orc_extractor* left, const orc_extractor* right,
                         const int32_t* best_dist, const int32_t* best_idx,
                         float bf, float min_d, float max_d, float* uright, float* depth, int32_t* sad);
 
+/* cv::cvtColor(src, dst, CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) for 8-bit images, the conversion of
+ * src/Tracking.cc:254-267 (OpenCV 2.4 / 3.x modules/imgproc/src/color.cpp, RGB2Gray<uchar>: Q14 weights R 4899, G 9617,
+ * B 1868, (sum + 2^13) >> 14).  channels 3 or 4 (the fourth is ignored), blue_first 1 for BGR / BGRA order. */
+void  orc_cvt_color_to_gray(const uint8_t* src, int w, int h, ptrdiff_t src_stride, int channels, int blue_first,
+                            uint8_t* dst, ptrdiff_t dst_stride);
+
 /* MapPoint::ComputeDistinctiveDescriptors selection, src/MapPoint.cc:513-547: of the n descriptors of one map point, the
  * index of the one with the least median Hamming distance to the set (median = sorted row [(int)(0.5*(n-1))], the
  * row including the zero distance to itself; first index wins ties).  -1 for n == 0. */

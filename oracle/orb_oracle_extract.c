@@ -920,3 +920,18 @@ void orc_stereo_refine(const orc_extractor* left, const orc_extractor* right,
     }
     free(v);
 }
+
+/* cv::cvtColor to grey, 8-bit: OpenCV builds three 256-entry tables tab[i] = i*coeff (the red one offset by 2^13) and
+ * sums one entry of each, which is this expression (modules/imgproc/src/color.cpp, RGB2Gray<uchar>, yuv_shift = 14). */
+void orc_cvt_color_to_gray(const uint8_t* src, int w, int h, ptrdiff_t src_stride, int channels, int blue_first,
+                           uint8_t* dst, ptrdiff_t dst_stride)
+{
+    const int R2Y = 4899, G2Y = 9617, B2Y = 1868;
+    const int c0 = blue_first ? B2Y : R2Y, c2 = blue_first ? R2Y : B2Y;
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* s = src + y * src_stride;
+        uint8_t* d = dst + y * dst_stride;
+        for (int x = 0; x < w; ++x, s += channels)
+            d[x] = (uint8_t)((s[0] * c0 + s[1] * G2Y + s[2] * c2 + (1 << 13)) >> 14);
+    }
+}

@@ -101,6 +101,18 @@ int main(int argc, char** argv)
     for (int i = 0; i < 9 && i < nm; ++i) vObs.push_back(d1.row(i * 7 % d1.rows));
     const int bestObs = matcher.DistinctiveDescriptor(vObs);
 
+    // colour frame straight into operator() (the cvtColor of src/Tracking.cc:254-267 fused into the extractor)
+    cv::Mat imBGR(h, w * 3, CV_8UC1), planes[3] = {cv::Mat(h, w, CV_8UC1), cv::Mat(h, w, CV_8UC1), cv::Mat(h, w, CV_8UC1)};
+    for (int c = 0; c < 3; ++c) orbx_synth_frame(70 + c, w, h, planes[c].ptr(), (ptrdiff_t)planes[c].step);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c) imBGR.at<unsigned char>(y, 3 * x + c) = planes[c].at<unsigned char>(y, x);
+    ORB_SLAM2::ORBextractor colourExtractor(1000, 1.2f, 8, 20, 7);
+    colourExtractor.SetInputFormat(ORBX_INPUT_BGR);
+    std::vector<cv::KeyPoint> kC;
+    cv::Mat dC;
+    colourExtractor(imBGR, cv::Mat(), kC, dC);
+
     FILE* f = fopen(argv[1], "wb");
     if (!f) return 4;
     int hdr[8] = {(int)k1.size(), (int)k2.size(), nm, dist, pyr3.cols, pyr3.rows, pyr3_step, ini->GetLevels()};
@@ -130,6 +142,10 @@ int main(int argc, char** argv)
         dump(f, &selfScore, 8); dump(f, &crossScore, 8);
         const int nobs = (int)vObs.size();
         dump(f, &nobs, 4); dump(f, &bestObs, 4);
+        const int nC = (int)kC.size();
+        dump(f, &nC, 4);
+        dump(f, kC.data(), kC.size() * sizeof(cv::KeyPoint));
+        dump(f, dC.ptr(), (size_t)dC.rows * 32);
     }
     fclose(f);
     {   // Frame::ComputeBoW latency (information only)

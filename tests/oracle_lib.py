@@ -380,3 +380,14 @@ def vocabulary_transform(k, L, parent, is_leaf, descriptors, weight, desc, level
     if rc:
         raise ValueError("malformed vocabulary tree")
     return word[:n], node[:n], ids[:nw.value], vals[:nw.value], fn[:nn.value], fp[:nn.value + 1], ff[:fp[nn.value]]
+
+
+lib.orc_cvt_color_to_gray.restype = None; lib.orc_cvt_color_to_gray.argtypes = [_vp, _i, _i, _pd, _i, _i, _vp, _pd]
+
+
+def cvt_color_to_gray(img, blue_first):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, c = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib.orc_cvt_color_to_gray(_ptr(img), w, h, img.strides[0], c, 1 if blue_first else 0, _ptr(out), out.strides[0])
+    return out

@@ -39,7 +39,10 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
         nid, cnt = np.frombuffer(raw, np.uint32, 2, off); off += 8
         fv_nodes.append(int(nid)); fv_lists.append(np.frombuffer(raw, np.uint32, int(cnt), off)); off += int(cnt) * 4
     self_score, cross_score = np.frombuffer(raw, np.float64, 2, off); off += 16
-    nobs, best_obs = np.frombuffer(raw, np.int32, 2, off)
+    nobs, best_obs = np.frombuffer(raw, np.int32, 2, off); off += 8
+    n_c = int(np.frombuffer(raw, np.int32, 1, off)[0]); off += 4
+    k_c = np.frombuffer(raw, vsa.KEYPOINT_DTYPE, n_c, off); off += n_c * 28
+    d_c = np.frombuffer(raw, np.uint8, n_c * 32, off).reshape(n_c, 32)
 
     w, h = 640, 480
     im1 = vsa.synth_frame(12, w, h)
@@ -91,3 +94,8 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
     # MapPoint::ComputeDistinctiveDescriptors through ORBmatcher::DistinctiveDescriptor
     obs = od1[[i * 7 % len(od1) for i in range(nobs)]]
     assert nobs == 9 and best_obs == oracle.distinctive_descriptor(obs)
+
+    # BGR frame through ORBextractor::SetInputFormat(ORBX_INPUT_BGR)
+    bgr = np.stack([vsa.synth_frame(70 + c, w, h) for c in range(3)], axis=2)
+    okc, odc = oracle.Extractor(oracle.make_params(1000)).extract(oracle.cvt_color_to_gray(bgr, blue_first=True))
+    assert n_c == len(okc) and np.array_equal(k_c, okc.astype(vsa.KEYPOINT_DTYPE)) and np.array_equal(d_c, odc)

@@ -195,3 +195,31 @@ def test_random_geometries(vsa, oracle):
         assert np.array_equal(desc, odesc), tag
         ran += 1
     assert ran >= 20
+
+
+@pytest.mark.parametrize("fmt", ["rgb", "bgr", "rgba", "bgra"])
+def test_colour_input(vsa, oracle, fmt):
+    """Colour frames straight into the extractor: the grey conversion of src/Tracking.cc:254-267 happens in the first
+    pyramid kernel.  Level 0 and the final outputs equal the oracle's on the oracle-converted image (host and batch paths,
+    widths that end in a partial 16-pixel chunk)."""
+    for w, h in ((640, 480), (331, 207)):
+        rng = np.random.default_rng(w)
+        chans = [vsa.synth_frame(70 + c, w, h) for c in range(3)]
+        img = np.stack(chans + ([rng.integers(0, 256, (h, w), dtype=np.uint8)] if len(fmt) == 4 else []), axis=2)
+        grey = oracle.cvt_color_to_gray(img, blue_first=fmt.startswith("b"))
+        p = vsa.make_params(800, 1.2, 6)
+        ex = vsa.Extractor(p, w, h, max_batch=3, device=0)
+        ex.set_input_format(fmt)
+        kps, desc = ex.extract(img)
+        assert np.array_equal(ex.pyramid_level(0, 0)[19:-19, 19:-19], grey)
+        okps, odesc = oracle.Extractor(oracle.make_params(800, 1.2, 6)).extract(grey)
+        assert len(kps) == len(okps) > 100
+        assert np.array_equal(kps, okps.astype(vsa.KEYPOINT_DTYPE)) and np.array_equal(desc, odesc)
+        bk, bd, bc = ex.extract_batch(np.stack([img, img[::-1].copy(), img]))
+        assert bc[0] == bc[2] == len(okps) and np.array_equal(bd[0][:bc[0]], odesc) and np.array_equal(bd[2][:bc[2]], odesc)
+        o2k, o2d = oracle.Extractor(oracle.make_params(800, 1.2, 6)).extract(np.ascontiguousarray(grey[::-1]))
+        assert bc[1] == len(o2k) and np.array_equal(bd[1][:bc[1]], o2d)
+        ex.set_input_format("gray")                      # and back: the same context on grey input again
+        k3, d3 = ex.extract(grey)
+        assert np.array_equal(d3, odesc)
+        ex.close()

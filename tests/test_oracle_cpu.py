@@ -260,3 +260,12 @@ def test_vocabulary_transform_known_answers(oracle):
     w0 = weight.copy(); w0[4] = 0.0
     r = oracle.vocabulary_transform(2, 2, parent, leaf, desc, w0, feats, 1)
     assert list(r[2]) == [0, 1] and list(r[6]) == [0, 3, 1]
+
+
+def test_cvt_color_known_answers(oracle):
+    """The 8-bit grey values cv::cvtColor is known for: pure red 76, green 150, blue 29, white 255, black 0."""
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [10, 200, 77]]], np.uint8)
+    assert list(oracle.cvt_color_to_gray(px, blue_first=False)[0]) == [76, 150, 29, 255, 0, (10 * 4899 + 200 * 9617 + 77 * 1868 + 8192) >> 14]
+    assert list(oracle.cvt_color_to_gray(px, blue_first=True)[0][:3]) == [29, 150, 76]
+    rgba = np.concatenate([px, np.full((1, 6, 1), 99, np.uint8)], axis=2)
+    assert np.array_equal(oracle.cvt_color_to_gray(rgba, False), oracle.cvt_color_to_gray(px, False))

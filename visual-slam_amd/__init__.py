@@ -57,6 +57,7 @@ _SIGS = {
     "orbx_scale_tables": (_i, [C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp]),
     "orbx_level_size": (_i, [C.POINTER(Params), _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "orbx_keypoint_capacity": (_i, [C.POINTER(Params), _i, _i]),
+    "orbx_extractor_set_input_format": (_i, [_vp, _i]),
     "orbx_extract": (_i, [_vp, _vp, _pd, _vp, _vp, _i, C.POINTER(_i)]),
     "orbx_extract_batch": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i, _vp]),
@@ -224,6 +225,18 @@ class Extractor:
         h = C.c_void_p()
         _check(lib.orbx_extractor_create(C.byref(params), width, height, max_batch, device, C.byref(h)))
         self.h = h
+        self.channels = 1
+
+    FORMATS = {"gray": (0, 1), "rgb": (1, 3), "bgr": (2, 3), "rgba": (3, 4), "bgra": (4, 4)}
+
+    def set_input_format(self, name):
+        """Input layout of the extract calls: "gray" (default) or interleaved "rgb" / "bgr" / "rgba" / "bgra"."""
+        code, ch = self.FORMATS[name]
+        _check(lib.orbx_extractor_set_input_format(self.h, code))
+        self.channels = ch
+
+    def _image_shape(self):
+        return (self.height, self.width) if self.channels == 1 else (self.height, self.width, self.channels)
 
     def close(self):
         if getattr(self, "h", None) and lib is not None:      # lib is None while the interpreter shuts down
@@ -234,7 +247,7 @@ class Extractor:
 
     def extract(self, img):
         img = np.ascontiguousarray(img, np.uint8)
-        assert img.shape == (self.height, self.width)
+        assert img.shape == self._image_shape()
         kps = np.zeros(self.cap, KEYPOINT_DTYPE)
         desc = np.zeros((self.cap, 32), np.uint8)
         n = C.c_int()
@@ -244,7 +257,7 @@ class Extractor:
     def extract_batch(self, imgs):
         imgs = np.ascontiguousarray(imgs, np.uint8)
         b = imgs.shape[0]
-        assert imgs.shape[1:] == (self.height, self.width)
+        assert imgs.shape[1:] == self._image_shape()
         kps = np.zeros((b, self.cap), KEYPOINT_DTYPE)
         desc = np.zeros((b, self.cap, 32), np.uint8)
         counts = np.zeros(b, np.int32)

@@ -37,12 +37,20 @@ void ORBextractor::SetBlurRounding(int mode)
     if (mode != mParams.blur_rounding) { orbx_extractor_destroy(mpContext); mpContext = nullptr; mParams.blur_rounding = mode; }
 }
 
+void ORBextractor::SetInputFormat(int format)
+{
+    if (format < ORBX_INPUT_GRAY || format > ORBX_INPUT_BGRA) throw std::runtime_error("ORBextractor: unknown input format");
+    mnFormat = format;
+    if (mpContext) check(orbx_extractor_set_input_format(mpContext, format), "ORBextractor: input format");
+}
+
 void ORBextractor::EnsureContext(int width, int height)
 {
     if (mpContext && width == mnWidth && height == mnHeight) return;
     orbx_extractor_destroy(mpContext);
     mpContext = nullptr;
     check(orbx_extractor_create(&mParams, width, height, 1, mnDevice, &mpContext), "ORBextractor: context");
+    check(orbx_extractor_set_input_format(mpContext, mnFormat), "ORBextractor: input format");
     mnWidth = width; mnHeight = height;
     mvStaging.resize(orbx_keypoint_capacity(&mParams, width, height));
 }
@@ -53,8 +61,16 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (_image.empty())
         return;
     const cv::Mat& image = _image;
-    if (image.type() != CV_8UC1) throw std::runtime_error("ORBextractor: image must be CV_8UC1");
-    EnsureContext(image.cols, image.rows);
+    const int channels = mnFormat == ORBX_INPUT_GRAY ? 1 : (mnFormat <= ORBX_INPUT_BGR ? 3 : 4);
+#ifdef ORBX_WITH_OPENCV
+    if (image.type() != CV_8UC(channels)) throw std::runtime_error("ORBextractor: image type does not match the input format");
+    const int width = image.cols;
+#else
+    // the stand-in Mat counts bytes: a colour image is passed as a matrix of width * channels columns
+    if (image.type() != CV_8UC1 || image.cols % channels) throw std::runtime_error("ORBextractor: image must be 8-bit, width * channels columns");
+    const int width = image.cols / channels;
+#endif
+    EnsureContext(width, image.rows);
 
     const int cap = (int)mvStaging.size();
     cv::Mat desc(cap, 32, CV_8U);
@@ -78,7 +94,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (mbDownloadPyramid) {
         for (int level = 0; level < nlevels; ++level) {
             int w = 0, h = 0;
-            check(orbx_level_size(&mParams, image.cols, image.rows, level, &w, &h), "ORBextractor: level size");
+            check(orbx_level_size(&mParams, width, image.rows, level, &w, &h), "ORBextractor: level size");
             cv::Mat temp(h + 38, w + 38, CV_8UC1);
             check(orbx_pyramid_level(mpContext, 0, level, temp.ptr(), (ptrdiff_t)temp.step), "ORBextractor: pyramid");
             mvImagePyramid[level] = temp(cv::Rect(19, 19, w, h));

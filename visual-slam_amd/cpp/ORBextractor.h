@@ -44,6 +44,9 @@ public:
     // rounding (orbx_params::blur_rounding).
     void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
     void SetDevice(int device);
+    // Colour frames straight into operator(): ORBX_INPUT_RGB / BGR / RGBA / BGRA make the first pyramid kernel apply the
+    // grey conversion Tracking::GrabImage* does on the host (src/Tracking.cc:254-267), so that call site can drop its cvtColor.
+    void SetInputFormat(int format);
     void SetBlurRounding(int mode);
     orbx_extractor* Handle() { return mpContext; }
     int ImageHeight() const { return mnHeight; }    // mvImagePyramid[0].rows of the last operator() call
@@ -62,6 +65,7 @@ protected:
 
     orbx_params mParams;
     orbx_extractor* mpContext = nullptr;
+    int mnFormat = ORBX_INPUT_GRAY;
     int mnWidth = 0, mnHeight = 0, mnDevice = -1;
     bool mbDownloadPyramid = true;
     std::vector<orbx_keypoint> mvStaging;

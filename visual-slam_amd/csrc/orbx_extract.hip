@@ -128,6 +128,54 @@ __device__ __forceinline__ void store_chunk_with_frame(uint8_t* roi, int stride,
     }
 }
 
+// cv::cvtColor to grey for 8-bit pixels (the conversion Tracking::GrabImage* applies before extraction,
+// src/Tracking.cc:254-267): (c0*p0 + c1*p1 + c2*p2 + 2^13) >> 14 with the Q14 weights R 4899, G 9617, B 1868
+// in the channel order of the input; a fourth channel is ignored.
+template <int CH> __device__ __forceinline__ uint32_t grey_at(const uint8_t* row, int x, int c0, int c1, int c2)
+{
+    if (CH == 1) return row[x];
+    const uint8_t* p = row + CH * x;
+    return (uint32_t)(p[0] * c0 + p[1] * c1 + p[2] * c2 + 8192) >> 14;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_level0_colour(const uint8_t* __restrict__ img, long long row_stride, long long frame_stride,
+                                                       uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L, int n_frames,
+                                                       int c0, int c1, int c2)
+{
+    int frame; uint32_t blk;
+    if (!frame_chunk(blockIdx.x, (L.cpr * L.h + 255) >> 8, n_frames, frame, blk)) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= (uint32_t)(L.cpr * L.h)) return;
+    uint32_t y, ch;
+    split_index(i, L.cpr, L.cpr_magic, y, ch);
+    const uint8_t* row = img + (long long)frame * frame_stride + (long long)y * row_stride;
+    uint32_t t[4] = {0, 0, 0, 0};
+    if ((int)(16 * ch + 16) <= L.w) {
+        // 16 pixels = CH*4 dwords; the byte positions are compile-time constants, so each channel is one bit-field extract
+        uint32_t d[CH * 4];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const u128_unaligned v = *reinterpret_cast<const u128_unaligned*>(row + CH * 16 * ch + 16 * k);
+            d[4 * k] = v.x; d[4 * k + 1] = v.y; d[4 * k + 2] = v.z; d[4 * k + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int b = CH * k;
+            const uint32_t p0 = (d[b >> 2] >> (8 * (b & 3))) & 255u, p1 = (d[(b + 1) >> 2] >> (8 * ((b + 1) & 3))) & 255u,
+                           p2 = (d[(b + 2) >> 2] >> (8 * ((b + 2) & 3))) & 255u;
+            t[k >> 2] |= ((p0 * c0 + p1 * c1 + p2 * c2 + 8192u) >> 14) << (8 * (k & 3));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int x = (int)(16 * ch) + k;
+            if (x < L.w + kFrameFill) t[k >> 2] |= grey_at<CH>(row, reflect101(x, L.w), c0, c1, c2) << (8 * (k & 3));
+        }
+    }
+    store_chunk_with_frame(pyr + (unsigned long long)frame * pyr_bytes + L.roi, L.stride, L.h, y, ch, make_uint4(t[0], t[1], t[2], t[3]));
+}
+
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img, long long row_stride, long long frame_stride,
                                                 uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L, int n_frames)
 {
@@ -1163,6 +1211,7 @@ struct orbx_extractor {
     int32_t* d_lvlcnt = nullptr;
     // staging for the host entry points
     uint8_t* d_img = nullptr;
+    int channels = 1, c0 = 0, c1 = 0, c2 = 0;   // input layout: interleaved channels and their Q14 grey weights
     orbx_keypoint* d_okp = nullptr;
     uint8_t* d_odesc = nullptr;
     int32_t* d_ocount = nullptr;
@@ -1335,8 +1384,15 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     {
         const DevLevel& L0 = ex->hlv[0];
         dim3 grid(frame_chunk_grid((L0.cpr * L0.h + 255) / 256, B));
-        hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
-                           pyr, (unsigned long long)G.pyr_bytes, L0, B);
+        if (ex->channels == 1)
+            hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
+                               pyr, (unsigned long long)G.pyr_bytes, L0, B);
+        else if (ex->channels == 3)
+            hipLaunchKernelGGL(k_level0_colour<3>, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
+                               pyr, (unsigned long long)G.pyr_bytes, L0, B, ex->c0, ex->c1, ex->c2);
+        else
+            hipLaunchKernelGGL(k_level0_colour<4>, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
+                               pyr, (unsigned long long)G.pyr_bytes, L0, B, ex->c0, ex->c1, ex->c2);
         for (int l = 1; l < G.nlevels; ++l) {
             const DevLevel& D = ex->hlv[l];
             if (D.fast_resize) {
@@ -1402,7 +1458,7 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
 {
     if (!ex || !d_images || !d_kps || !d_desc || !d_counts) { set_error("orbx_extract_batch_device: null pointer"); return ORBX_ERR_BAD_ARG; }
     if (n_frames < 1 || n_frames > ex->max_batch) { set_error("n_frames outside [1, max_batch]"); return ORBX_ERR_BAD_ARG; }
-    if (row_stride < ex->geo.width || cap_per_frame < 1) { set_error("row_stride < width or cap_per_frame < 1"); return ORBX_ERR_BAD_ARG; }
+    if (row_stride < (ptrdiff_t)ex->geo.width * ex->channels || cap_per_frame < 1) { set_error("row_stride < width * channels or cap_per_frame < 1"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipSetDevice(ex->device));
     const int rc = launch_frames(ex, (hipStream_t)stream, 0, n_frames, ex->profiling, d_images, row_stride, frame_stride, d_kps, d_desc,
                                  d_counts, cap_per_frame);
@@ -1410,17 +1466,37 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
     return rc;
 }
 
+int orbx_extractor_set_input_format(orbx_extractor* ex, int format)
+{
+    if (!ex || format < ORBX_INPUT_GRAY || format > ORBX_INPUT_BGRA) { set_error("orbx_extractor_set_input_format: bad argument"); return ORBX_ERR_BAD_ARG; }
+    const int channels = format == ORBX_INPUT_GRAY ? 1 : (format == ORBX_INPUT_RGB || format == ORBX_INPUT_BGR ? 3 : 4);
+    const bool blue_first = format == ORBX_INPUT_BGR || format == ORBX_INPUT_BGRA;
+    HIP_CHECK(hipSetDevice(ex->device));
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    if (channels != ex->channels) {              // the image staging buffers are sized by the input layout
+        if (ex->d_img) (void)hipFree(ex->d_img);
+        if (ex->h_img) (void)hipHostFree(ex->h_img);
+        ex->d_img = nullptr; ex->h_img = nullptr;
+        for (void** p : {(void**)&ex->d_okp, (void**)&ex->d_odesc, (void**)&ex->d_ocount}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (void** p : {(void**)&ex->h_okp, (void**)&ex->h_odesc, (void**)&ex->h_ocount}) { if (*p) (void)hipHostFree(*p); *p = nullptr; }
+    }
+    if (ex->graph1) { (void)hipGraphExecDestroy(ex->graph1); ex->graph1 = nullptr; }   // captured with the old first kernel
+    ex->channels = channels;
+    ex->c0 = blue_first ? 1868 : 4899; ex->c1 = 9617; ex->c2 = blue_first ? 4899 : 1868;   // B2Y, G2Y, R2Y in Q14
+    return ORBX_OK;
+}
+
 static int ensure_staging(orbx_extractor* ex)
 {
     if (ex->d_img) return ORBX_OK;
     const size_t B = (size_t)ex->max_batch;
     const Geometry& G = ex->geo;
-    HIP_CHECK(hipMalloc(&ex->d_img, (size_t)G.width * G.height * B + 16));
+    HIP_CHECK(hipMalloc(&ex->d_img, (size_t)G.width * G.height * ex->channels * B + 16));
     HIP_CHECK(hipMalloc(&ex->d_okp, sizeof(orbx_keypoint) * (size_t)G.out_cap * B));
     HIP_CHECK(hipMalloc(&ex->d_odesc, (size_t)32 * G.out_cap * B));
     HIP_CHECK(hipMalloc(&ex->d_ocount, sizeof(int32_t) * B));
     // pinned mirrors: pageable 2-D copies cost milliseconds per frame, pinned 1-D copies tens of microseconds
-    HIP_CHECK(hipHostMalloc(&ex->h_img, (size_t)G.width * G.height * B + 16, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&ex->h_img, (size_t)G.width * G.height * ex->channels * B + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc(&ex->h_okp, sizeof(orbx_keypoint) * (size_t)G.out_cap * B, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc(&ex->h_odesc, (size_t)32 * G.out_cap * B, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc(&ex->h_ocount, sizeof(int32_t) * B, hipHostMallocDefault));
@@ -1432,23 +1508,23 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_
 {
     if (!ex || !images || !kps || !desc || !counts) { set_error("orbx_extract_batch: null pointer"); return ORBX_ERR_BAD_ARG; }
     if (n_frames < 1 || n_frames > ex->max_batch) { set_error("n_frames outside [1, max_batch]"); return ORBX_ERR_BAD_ARG; }
-    if (row_stride < ex->geo.width) { set_error("row_stride < width"); return ORBX_ERR_BAD_ARG; }
+    if (row_stride < (ptrdiff_t)ex->geo.width * ex->channels) { set_error("row_stride < width * channels"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipSetDevice(ex->device));
     int rc = ensure_staging(ex);
     if (rc) return rc;
     const Geometry& G = ex->geo;
-    const size_t fbytes = (size_t)G.width * G.height;
+    const size_t rbytes = (size_t)G.width * ex->channels, fbytes = rbytes * G.height;
     for (int f = 0; f < n_frames; ++f) {
         const uint8_t* src = images + (ptrdiff_t)f * frame_stride;
         uint8_t* dst = ex->h_img + f * fbytes;
-        if (row_stride == G.width) std::memcpy(dst, src, fbytes);
-        else for (int y = 0; y < G.height; ++y) std::memcpy(dst + (size_t)y * G.width, src + (ptrdiff_t)y * row_stride, G.width);
+        if ((size_t)row_stride == rbytes) std::memcpy(dst, src, fbytes);
+        else for (int y = 0; y < G.height; ++y) std::memcpy(dst + (size_t)y * rbytes, src + (ptrdiff_t)y * row_stride, rbytes);
     }
     // a few frames: one round trip (counts and whole output slots together); many frames: counts first, then what is used
     const bool one_trip = n_frames <= 8;
     auto enqueue = [&]() -> int {
         HIP_CHECK(hipMemcpyAsync(ex->d_img, ex->h_img, fbytes * n_frames, hipMemcpyHostToDevice, ex->stream));
-        const int r = launch_frames(ex, ex->stream, 0, n_frames, ex->profiling, ex->d_img, G.width, (ptrdiff_t)fbytes, ex->d_okp, ex->d_odesc,
+        const int r = launch_frames(ex, ex->stream, 0, n_frames, ex->profiling, ex->d_img, (ptrdiff_t)rbytes, (ptrdiff_t)fbytes, ex->d_okp, ex->d_odesc,
                                     ex->d_ocount, G.out_cap);
         if (r) return r;
         HIP_CHECK(hipMemcpyAsync(ex->h_ocount, ex->d_ocount, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, ex->stream));
