@@ -97,6 +97,21 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
                               ptrdiff_t frame_stride, int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc,
                               int32_t* d_counts, int cap_per_frame, void* stream);
 
+/* Pinhole camera with the radial-tangential model of the reference's settings files (Camera.fx .. Camera.k3,
+ * src/Tracking.cc:56-80): K = [fx 0 cx; 0 fy cy; 0 0 1] and dist = k1, k2, p1, p2, k3 as mK / mDistCoef hold them (floats). */
+typedef struct orbx_camera { float fx, fy, cx, cy; float k1, k2, p1, p2, k3; } orbx_camera;
+/* Frame::UndistortKeyPoints (src/Frame.cc:404-434) on the output of a batched extraction: cv::undistortPoints(pts, pts,
+ * mK, mDistCoef, Mat(), mK), i.e. normalise, five fixed-point iterations of the inverse distortion in double, project
+ * back through K, round to float.  d_kps_un receives copies of the keypoints with pt replaced (mvKeysUn); with
+ * cam->k1 == 0 they are plain copies, as in the reference (:406-410).  Layout as orbx_extract_batch_device leaves it
+ * (blocks of cap_per_frame, d_counts valid rows each).  Asynchronous on `stream`. */
+int orbx_undistort_keypoints_batch_device(orbx_extractor* ex, const orbx_camera* cam, const orbx_keypoint* d_kps,
+                                          const int32_t* d_counts, int cap_per_frame, int n_frames,
+                                          orbx_keypoint* d_kps_un, void* stream);
+/* The same for n host points (x, y pairs), e.g. one frame's keypoints or the four image corners of
+ * Frame::ComputeImageBounds (src/Frame.cc:436-456); unlike the call above it always undistorts.  Synchronous. */
+int orbx_undistort_points(orbx_extractor* ex, const orbx_camera* cam, const float* xy, int n, float* xy_out);
+
 /* mvImagePyramid[level] of frame `frame` of the last batch (include/ORBextractor.h:150): the padded
  * (w+38) x (h+38) buffer is copied to dst (host); the image ROI starts at row 19, column 19. */
 int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride);

@@ -161,6 +161,12 @@ void  orc_stereo_refine(const orc_extractor* left, const orc_extractor* right,
 void  orc_cvt_color_to_gray(const uint8_t* src, int w, int h, ptrdiff_t src_stride, int channels, int blue_first,
                             uint8_t* dst, ptrdiff_t dst_stride);
 
+/* cv::undistortPoints(src, dst, K, dist, noArray(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call it
+ * (src/Frame.cc:404-456), OpenCV 2.4.9 - 3.4.1 modules/imgproc/src/undistort.cpp cvUndistortPoints: K and k1,k2,p1,p2,k3
+ * widened to double, five iterations, projection through P = K, result rounded to float.  xy / xy_out: n (x, y) pairs. */
+void  orc_undistort_points(const float* xy, int n, float fx, float fy, float cx, float cy,
+                           float k1, float k2, float p1, float p2, float k3, float* xy_out);
+
 /* MapPoint::ComputeDistinctiveDescriptors selection, src/MapPoint.cc:513-547: of the n descriptors of one map point, the
  * index of the one with the least median Hamming distance to the set (median = sorted row [(int)(0.5*(n-1))], the
  * row including the zero distance to itself; first index wins ties).  -1 for n == 0. */

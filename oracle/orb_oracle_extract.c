@@ -935,3 +935,32 @@ void orc_cvt_color_to_gray(const uint8_t* src, int w, int h, ptrdiff_t src_strid
             d[x] = (uint8_t)((s[0] * c0 + s[1] * G2Y + s[2] * c2 + (1 << 13)) >> 14);
     }
 }
+
+/* cvUndistortPoints without R, with P = K (modules/imgproc/src/undistort.cpp).  k[] holds k1,k2,p1,p2,k3 and zeros for the
+ * rational terms k4..k6, so the numerator of icdist is 1 + 0 = 1.  RR = P * I has exact entries fx, 0, cx / 0, fy, cy / 0, 0, 1. */
+void orc_undistort_points(const float* xy, int n, float ffx, float ffy, float fcx, float fcy,
+                          float fk1, float fk2, float fp1, float fp2, float fk3, float* xy_out)
+{
+    const double fx = ffx, fy = ffy, cx = fcx, cy = fcy;
+    const double k[8] = {fk1, fk2, fp1, fp2, fk3, 0, 0, 0};
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double RR[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}};
+    for (int i = 0; i < n; ++i) {
+        double x = xy[2 * i], y = xy[2 * i + 1], x0, y0;
+        x0 = x = (x - cx) * ifx;
+        y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+        const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+        const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        xy_out[2 * i] = (float)(xx * ww);
+        xy_out[2 * i + 1] = (float)(yy * ww);
+    }
+}

@@ -391,3 +391,13 @@ def cvt_color_to_gray(img, blue_first):
     out = np.zeros((h, w), np.uint8)
     lib.orc_cvt_color_to_gray(_ptr(img), w, h, img.strides[0], c, 1 if blue_first else 0, _ptr(out), out.strides[0])
     return out
+
+
+lib.orc_undistort_points.restype = None; lib.orc_undistort_points.argtypes = [_vp, _i] + [_f] * 9 + [_vp]
+
+
+def undistort_points(xy, fx, fy, cx, cy, k1, k2, p1, p2, k3):
+    xy = np.ascontiguousarray(xy, np.float32)
+    out = np.zeros_like(xy)
+    lib.orc_undistort_points(_ptr(xy), xy.shape[0], fx, fy, cx, cy, k1, k2, p1, p2, k3, _ptr(out))
+    return out

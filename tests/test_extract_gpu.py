@@ -223,3 +223,43 @@ def test_colour_input(vsa, oracle, fmt):
         k3, d3 = ex.extract(grey)
         assert np.array_equal(d3, odesc)
         ex.close()
+
+
+def test_undistort_keypoints(vsa, oracle):
+    """Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:404-456) on the device: coordinates bit-exact against
+    the oracle's double-precision restatement of cv::undistortPoints; the batch form on the extractor's own output."""
+    import torch
+    w, h = 640, 480
+    cams = [vsa.Camera(517.306408, 516.469215, 318.643040, 255.313989, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314),   # TUM1.yaml
+            vsa.Camera(535.4, 539.2, 320.1, 247.6, 0.0, 0.0, 0.0, 0.0, 0.0),                                                  # TUM3.yaml: no distortion
+            vsa.Camera(458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)]         # EuRoC.yaml
+    ex = vsa.Extractor(vsa.make_params(), w, h, max_batch=3, device=0)
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([np.array([[0, 0], [w, 0], [0, h], [w, h]], np.float32),
+                          np.stack([rng.uniform(-50, 700, 5000), rng.uniform(-50, 530, 5000)], 1).astype(np.float32)])
+    for cam in cams:
+        args = [getattr(cam, n) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+        got = ex.undistort_points(cam, pts)
+        want = oracle.undistort_points(pts, *args)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        # batch form behind a device-resident extraction
+        B = 3
+        imgs = torch.from_numpy(np.stack([vsa.synth_frame(40 + i, w, h) for i in range(B)])).cuda()
+        cap = ex.cap
+        d_k = torch.zeros(B * cap * 7, dtype=torch.float32, device="cuda"); d_u = torch.full_like(d_k, -7.0)
+        d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"); d_c = torch.zeros(B, dtype=torch.int32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        ex.extract_batch_device(imgs.data_ptr(), w, w * h, B, d_k.data_ptr(), d_d.data_ptr(), d_c.data_ptr(), cap, st)
+        ex.undistort_keypoints_batch_device(cam, d_k.data_ptr(), d_c.data_ptr(), cap, B, d_u.data_ptr(), st)
+        torch.cuda.synchronize()
+        k = d_k.cpu().numpy().view(vsa.KEYPOINT_DTYPE).reshape(B, cap); u = d_u.cpu().numpy().view(vsa.KEYPOINT_DTYPE).reshape(B, cap)
+        c = d_c.cpu().numpy()
+        for f in range(B):
+            kk, uu = k[f, :c[f]], u[f, :c[f]]
+            for name in ("size", "angle", "response", "octave", "class_id"):
+                assert np.array_equal(kk[name], uu[name])
+            xy = np.stack([kk["x"], kk["y"]], 1)
+            want = xy if cam.k1 == 0.0 else oracle.undistort_points(xy, *args)      # k1 == 0: mvKeysUn = mvKeys (:406-410)
+            assert np.array_equal(np.stack([uu["x"], uu["y"]], 1).view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+            assert np.all(u[f, c[f]:]["x"] == -7.0)                                # rows past the count untouched
+    ex.close()

@@ -269,3 +269,25 @@ def test_cvt_color_known_answers(oracle):
     assert list(oracle.cvt_color_to_gray(px, blue_first=True)[0][:3]) == [29, 150, 76]
     rgba = np.concatenate([px, np.full((1, 6, 1), 99, np.uint8)], axis=2)
     assert np.array_equal(oracle.cvt_color_to_gray(rgba, False), oracle.cvt_color_to_gray(px, False))
+
+
+def test_undistort_points_properties(oracle):
+    """No reference fixture exists for cv::undistortPoints here (parity unpinned); what can be checked by reasoning:
+    zero coefficients give the identity up to float rounding, the principal point is a fixed point, and distorting the
+    result with the forward model returns the input (the five iterations converge for the TUM1 camera)."""
+    fx, fy, cx, cy = 517.306408, 516.469215, 318.643040, 255.313989                     # Examples/Monocular/TUM1.yaml
+    k1, k2, p1, p2, k3 = 0.262383, -0.953104, -0.005358, 0.002628, 1.163314
+    rng = np.random.default_rng(0)
+    xy = np.stack([rng.uniform(0, 640, 500), rng.uniform(0, 480, 500)], 1).astype(np.float32)
+    ident = oracle.undistort_points(xy, fx, fy, cx, cy, 0, 0, 0, 0, 0)
+    assert np.abs(ident - xy).max() < 1e-4
+    centre = oracle.undistort_points(np.array([[cx, cy]], np.float32), fx, fy, cx, cy, k1, k2, p1, p2, k3)
+    assert np.allclose(centre, [[np.float32(cx), np.float32(cy)]], atol=1e-5)
+    un = oracle.undistort_points(xy, fx, fy, cx, cy, k1, k2, p1, p2, k3).astype(np.float64)
+    x = (un[:, 0] - np.float32(cx)) / np.float32(fx); y = (un[:, 1] - np.float32(cy)) / np.float32(fy)
+    r2 = x * x + y * y
+    cd = 1 + ((np.float32(k3) * r2 + np.float32(k2)) * r2 + np.float32(k1)) * r2
+    xd = x * cd + 2 * np.float32(p1) * x * y + np.float32(p2) * (r2 + 2 * x * x)
+    yd = y * cd + np.float32(p1) * (r2 + 2 * y * y) + 2 * np.float32(p2) * x * y
+    back = np.stack([xd * np.float32(fx) + np.float32(cx), yd * np.float32(fy) + np.float32(cy)], 1)
+    assert np.abs(back - xy).max() < 0.05

@@ -25,6 +25,11 @@ class Params(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("blur_rounding", C.c_int32)]
 
 
+class Camera(C.Structure):
+    """orbx_camera: pinhole intrinsics and k1, k2, p1, p2, k3."""
+    _fields_ = [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+
 class OrbxError(RuntimeError):
     def __init__(self, status, text):
         super().__init__(f"orbx status {status}: {text}")
@@ -58,6 +63,8 @@ _SIGS = {
     "orbx_level_size": (_i, [C.POINTER(Params), _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "orbx_keypoint_capacity": (_i, [C.POINTER(Params), _i, _i]),
     "orbx_extractor_set_input_format": (_i, [_vp, _i]),
+    "orbx_undistort_keypoints_batch_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "orbx_undistort_points": (_i, [_vp, _vp, _vp, _i, _vp]),
     "orbx_extract": (_i, [_vp, _vp, _pd, _vp, _vp, _i, C.POINTER(_i)]),
     "orbx_extract_batch": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i, _vp]),
@@ -266,6 +273,15 @@ class Extractor:
 
     def extract_batch_device(self, d_images, row_stride, frame_stride, n_frames, d_kps, d_desc, d_counts, cap, stream=None):
         _check(lib.orbx_extract_batch_device(self.h, d_images, row_stride, frame_stride, n_frames, d_kps, d_desc, d_counts, cap, stream))
+
+    def undistort_points(self, cam, xy):
+        xy = np.ascontiguousarray(xy, np.float32)
+        out = np.zeros_like(xy)
+        _check(lib.orbx_undistort_points(self.h, C.byref(cam), _ptr(xy), xy.shape[0], _ptr(out)))
+        return out
+
+    def undistort_keypoints_batch_device(self, cam, d_kps, d_counts, cap, n_frames, d_kps_un, stream=None):
+        _check(lib.orbx_undistort_keypoints_batch_device(self.h, C.byref(cam), d_kps, d_counts, cap, n_frames, d_kps_un, stream))
 
     def pyramid_level(self, frame, level):
         w, h = level_size(self.params, self.width, self.height, level)

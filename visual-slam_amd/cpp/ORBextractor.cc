@@ -2,6 +2,7 @@
 #include <stdexcept>
 #include <string>
 #include <cstring>
+#include <algorithm>
 
 namespace ORB_SLAM2
 {
@@ -53,6 +54,28 @@ void ORBextractor::EnsureContext(int width, int height)
     check(orbx_extractor_set_input_format(mpContext, mnFormat), "ORBextractor: input format");
     mnWidth = width; mnHeight = height;
     mvStaging.resize(orbx_keypoint_capacity(&mParams, width, height));
+}
+
+void ORBextractor::UndistortKeyPoints(const std::vector<cv::KeyPoint>& vKeys, const orbx_camera& cam, std::vector<cv::KeyPoint>& vKeysUn)
+{
+    vKeysUn = vKeys;
+    if (cam.k1 == 0.0f || vKeys.empty()) return;                        // src/Frame.cc:406-410
+    if (!mpContext) throw std::runtime_error("ORBextractor::UndistortKeyPoints: call operator() first");
+    std::vector<float> xy(vKeys.size() * 2), out(vKeys.size() * 2);
+    for (size_t i = 0; i < vKeys.size(); ++i) { xy[2 * i] = vKeys[i].pt.x; xy[2 * i + 1] = vKeys[i].pt.y; }
+    check(orbx_undistort_points(mpContext, &cam, xy.data(), (int)vKeys.size(), out.data()), "ORBextractor: undistort");
+    for (size_t i = 0; i < vKeys.size(); ++i) { vKeysUn[i].pt.x = out[2 * i]; vKeysUn[i].pt.y = out[2 * i + 1]; }
+}
+
+void ORBextractor::ComputeImageBounds(int cols, int rows, const orbx_camera& cam, float& minX, float& maxX, float& minY, float& maxY)
+{
+    if (cam.k1 == 0.0f) { minX = 0.0f; maxX = (float)cols; minY = 0.0f; maxY = (float)rows; return; }
+    if (!mpContext) throw std::runtime_error("ORBextractor::ComputeImageBounds: call operator() first");
+    const float corners[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+    float un[8];
+    check(orbx_undistort_points(mpContext, &cam, corners, 4, un), "ORBextractor: undistort");
+    minX = std::min(un[0], un[4]); maxX = std::max(un[2], un[6]);     // src/Frame.cc:451-454
+    minY = std::min(un[1], un[3]); maxY = std::max(un[5], un[7]);
 }
 
 void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,

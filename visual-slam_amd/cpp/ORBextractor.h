@@ -48,6 +48,11 @@ public:
     // grey conversion Tracking::GrabImage* does on the host (src/Tracking.cc:254-267), so that call site can drop its cvtColor.
     void SetInputFormat(int format);
     void SetBlurRounding(int mode);
+    // Frame::UndistortKeyPoints (src/Frame.cc:404-434) for the keypoints of the last operator() call's image size:
+    // cam = mK and mDistCoef (k3 = 0 when the settings file has none).  k1 == 0 copies, as the reference does.
+    void UndistortKeyPoints(const std::vector<cv::KeyPoint>& vKeys, const orbx_camera& cam, std::vector<cv::KeyPoint>& vKeysUn);
+    // Frame::ComputeImageBounds (src/Frame.cc:436-464) for an image of cols x rows
+    void ComputeImageBounds(int cols, int rows, const orbx_camera& cam, float& minX, float& maxX, float& minY, float& maxY);
     orbx_extractor* Handle() { return mpContext; }
     int ImageHeight() const { return mnHeight; }    // mvImagePyramid[0].rows of the last operator() call
 

@@ -1179,6 +1179,54 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict
     }
 }
 
+// cv::undistortPoints(src, dst, K, dist, noArray(), K) for the reference's camera model (OpenCV 2.4.9 - 3.4.1
+// cvUndistortPoints: K and the coefficients widened to double, five iterations, no early exit).  One thread per point;
+// every operation rounds on its own (the file is built with contraction off), as in a baseline x86-64 build of OpenCV.
+__device__ __forceinline__ void undistort_point(float px, float py, double fx, double fy, double cx, double cy,
+                                                double k1, double k2, double p1, double p2, double k3, float& ox, float& oy)
+{
+    const double ifx = 1.0 / fx, ify = 1.0 / fy;
+    double x = px, y = py;
+    const double x0 = x = (x - cx) * ifx;
+    const double y0 = y = (y - cy) * ify;
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        // the rational-model numerator (k4..k6 = 0) evaluates to exactly 1
+        const double icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+        const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+        const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    // projection through P = K: rows (fx 0 cx), (0 fy cy), (0 0 1), each evaluated left to right
+    const double xx = fx * x + 0.0 * y + cx;
+    const double yy = 0.0 * x + fy * y + cy;
+    const double ww = 1.0 / (0.0 * x + 0.0 * y + 1.0);
+    ox = (float)(xx * ww);
+    oy = (float)(yy * ww);
+}
+
+__global__ __launch_bounds__(256) void k_undistort_keypoints(const orbx_keypoint* __restrict__ kps, const int32_t* __restrict__ counts, int cap,
+                                                             orbx_camera cam, int copy_only, orbx_keypoint* __restrict__ out)
+{
+    const int frame = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(counts[frame], cap)) return;
+    orbx_keypoint k = kps[(size_t)frame * cap + i];
+    if (!copy_only) undistort_point(k.x, k.y, cam.fx, cam.fy, cam.cx, cam.cy, cam.k1, cam.k2, cam.p1, cam.p2, cam.k3, k.x, k.y);
+    out[(size_t)frame * cap + i] = k;
+}
+
+__global__ __launch_bounds__(256) void k_undistort_points(const float2* __restrict__ xy, int n, orbx_camera cam, float2* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 p = xy[i];
+    float2 o;
+    undistort_point(p.x, p.y, cam.fx, cam.fy, cam.cx, cam.cy, cam.k1, cam.k2, cam.p1, cam.p2, cam.k3, o.x, o.y);
+    out[i] = o;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1210,6 +1258,7 @@ struct orbx_extractor {
     uint32_t* d_lvlkp = nullptr;
     int32_t* d_lvlcnt = nullptr;
     // staging for the host entry points
+    float* d_pts = nullptr; float* h_pts = nullptr; int pts_cap = 0;   // staging of orbx_undistort_points
     uint8_t* d_img = nullptr;
     int channels = 1, c0 = 0, c1 = 0, c2 = 0;   // input layout: interleaved channels and their Q14 grey weights
     orbx_keypoint* d_okp = nullptr;
@@ -1353,10 +1402,10 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    void* ptrs[] = {ex->d_octmem, ex->d_lv, ex->d_cells, ex->d_cell_list, ex->d_rx, ex->d_ry, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
+    void* ptrs[] = {ex->d_pts, ex->d_octmem, ex->d_lv, ex->d_cells, ex->d_cell_list, ex->d_rx, ex->d_ry, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
                     ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    void* hptrs[] = {ex->h_img, ex->h_okp, ex->h_odesc, ex->h_ocount, ex->h_level};
+    void* hptrs[] = {ex->h_pts, ex->h_img, ex->h_okp, ex->h_odesc, ex->h_ocount, ex->h_level};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
     for (auto& e : ex->ev) if (e) (void)hipEventDestroy(e);
     if (ex->graph1) (void)hipGraphExecDestroy(ex->graph1);
@@ -1483,6 +1532,47 @@ int orbx_extractor_set_input_format(orbx_extractor* ex, int format)
     if (ex->graph1) { (void)hipGraphExecDestroy(ex->graph1); ex->graph1 = nullptr; }   // captured with the old first kernel
     ex->channels = channels;
     ex->c0 = blue_first ? 1868 : 4899; ex->c1 = 9617; ex->c2 = blue_first ? 4899 : 1868;   // B2Y, G2Y, R2Y in Q14
+    return ORBX_OK;
+}
+
+int orbx_undistort_keypoints_batch_device(orbx_extractor* ex, const orbx_camera* cam, const orbx_keypoint* d_kps, const int32_t* d_counts,
+                                          int cap_per_frame, int n_frames, orbx_keypoint* d_kps_un, void* stream)
+{
+    if (!ex || !cam || !d_kps || !d_counts || !d_kps_un || cap_per_frame < 1 || n_frames < 0) { set_error("orbx_undistort_keypoints_batch_device: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (n_frames == 0) return ORBX_OK;
+    if (!(cam->fx != 0.f) || !(cam->fy != 0.f)) { set_error("camera focal length is zero"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(ex->device));
+    hipLaunchKernelGGL(k_undistort_keypoints, dim3((cap_per_frame + 255) / 256, n_frames), dim3(256), 0, (hipStream_t)stream, d_kps, d_counts,
+                       cap_per_frame, *cam, cam->k1 == 0.0f ? 1 : 0, d_kps_un);
+    HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_undistort_points(orbx_extractor* ex, const orbx_camera* cam, const float* xy, int n, float* xy_out)
+{
+    if (!ex || !cam || n < 0) { set_error("orbx_undistort_points: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (n == 0) return ORBX_OK;
+    if (!xy || !xy_out) { set_error("orbx_undistort_points: null pointer"); return ORBX_ERR_BAD_ARG; }
+    if (!(cam->fx != 0.f) || !(cam->fy != 0.f)) { set_error("camera focal length is zero"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(ex->device));
+    if (ex->pts_cap < n) {
+        if (ex->d_pts) (void)hipFree(ex->d_pts);
+        if (ex->h_pts) (void)hipHostFree(ex->h_pts);
+        ex->d_pts = nullptr; ex->h_pts = nullptr; ex->pts_cap = 0;
+        const int cap = std::max(n, 4096);
+        HIP_CHECK(hipMalloc(&ex->d_pts, sizeof(float) * 4 * (size_t)cap));
+        HIP_CHECK(hipHostMalloc(&ex->h_pts, sizeof(float) * 4 * (size_t)cap, hipHostMallocDefault));
+        ex->pts_cap = cap;
+    }
+    std::memcpy(ex->h_pts, xy, sizeof(float) * 2 * (size_t)n);
+    HIP_CHECK(hipMemcpyAsync(ex->d_pts, ex->h_pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ex->stream));
+    hipLaunchKernelGGL(k_undistort_points, dim3((n + 255) / 256), dim3(256), 0, ex->stream, reinterpret_cast<const float2*>(ex->d_pts), n, *cam,
+                       reinterpret_cast<float2*>(ex->d_pts + 2 * (size_t)ex->pts_cap));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(ex->h_pts + 2 * (size_t)ex->pts_cap, ex->d_pts + 2 * (size_t)ex->pts_cap, sizeof(float) * 2 * (size_t)n,
+                             hipMemcpyDeviceToHost, ex->stream));
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    std::memcpy(xy_out, ex->h_pts + 2 * (size_t)ex->pts_cap, sizeof(float) * 2 * (size_t)n);
     return ORBX_OK;
 }
 
