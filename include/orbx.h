@@ -298,6 +298,23 @@ int orbx_stereo_refine(orbx_extractor* left, orbx_extractor* right,
                        float* uright, float* depth);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Stereo rectification ahead of extraction                                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* cv::remap(src, dst, M1, M2, cv::INTER_LINEAR) for 8-bit single-channel images with the two CV_32F maps that
+ * cv::initUndistortRectifyMap returns (Examples/Stereo/stereo_euroc.cc:97-98, 136-137): map_x / map_y give, per
+ * destination pixel, the source position (rows map_stride floats apart).  Fixed-point as in OpenCV: positions rounded
+ * to 1/32 pixel, Q15 weights, (sum + 2^14) >> 15, constant border 0.  The maps are converted once at create. */
+typedef struct orbx_remapper orbx_remapper;
+int orbx_remap_create(int device, const float* map_x, const float* map_y, ptrdiff_t map_stride, int dst_w, int dst_h,
+                      int src_w, int src_h, orbx_remapper** out);
+void orbx_remap_destroy(orbx_remapper* r);
+/* n_frames device-resident images (the output can be handed to orbx_extract_batch_device); asynchronous. */
+int orbx_remap_batch_device(orbx_remapper* r, const uint8_t* d_src, ptrdiff_t src_row_stride, ptrdiff_t src_frame_stride,
+                            int n_frames, uint8_t* d_dst, ptrdiff_t dst_row_stride, ptrdiff_t dst_frame_stride, void* stream);
+/* One host image; synchronous. */
+int orbx_remap_image(orbx_remapper* r, const uint8_t* src, ptrdiff_t src_stride, uint8_t* dst, ptrdiff_t dst_stride);
+
+/* ------------------------------------------------------------------------------------------ */
 /* The Hamming consumers that follow extraction                                                */
 /* ------------------------------------------------------------------------------------------ */
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:483-548), the selection at :513-542, for a batch of map

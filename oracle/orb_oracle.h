@@ -167,6 +167,13 @@ void  orc_cvt_color_to_gray(const uint8_t* src, int w, int h, ptrdiff_t src_stri
 void  orc_undistort_points(const float* xy, int n, float fx, float fy, float cx, float cy,
                            float k1, float k2, float p1, float p2, float k3, float* xy_out);
 
+/* cv::remap(src, dst, map_x, map_y, INTER_LINEAR, BORDER_CONSTANT, 0) for CV_8UC1 images and CV_32FC1 maps, the call of
+ * Examples/Stereo/stereo_euroc.cc:136-137 (OpenCV 2.4 / 3.x modules/imgproc/src/imgwarp.cpp: initInterTab2D's Q15
+ * bilinear table, RemapInvoker's conversion of the float maps to shorts + 1/32 fractions, remapBilinear). */
+void  orc_remap_linear_u8(const uint8_t* src, int sw, int sh, ptrdiff_t sstride,
+                          const float* map_x, const float* map_y, ptrdiff_t map_stride,
+                          uint8_t* dst, int dw, int dh, ptrdiff_t dstride);
+
 /* MapPoint::ComputeDistinctiveDescriptors selection, src/MapPoint.cc:513-547: of the n descriptors of one map point, the
  * index of the one with the least median Hamming distance to the set (median = sorted row [(int)(0.5*(n-1))], the
  * row including the zero distance to itself; first index wins ties).  -1 for n == 0. */

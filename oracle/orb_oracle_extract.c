@@ -30,8 +30,14 @@ static const int8_t k_pattern[1024] = {
 /* OpenCV scalar helpers                                                      */
 /* ------------------------------------------------------------------------- */
 
-/* cvRound: nearest integer, ties to even (lrint under the default rounding mode). */
-int orc_cv_round(double v) { return (int)lrint(v); }
+/* cvRound: nearest integer, ties to even.  On x86-64 OpenCV compiles it to the 32-bit cvtsd2si, which returns
+ * INT_MIN for NaN and for values no int can hold; lrint (64-bit there) would wrap differently, so that case is explicit. */
+int orc_cv_round(double v)
+{
+    if (!(v >= -2147483648.5 && v <= 2147483647.5)) return INT_MIN;
+    const double r = rint(v);
+    return r > 2147483647.0 || r < -2147483648.0 ? INT_MIN : (int)r;
+}
 static int cv_floor(double v) { int i = (int)v; return i - (i > v); }
 static int cv_ceil(double v)  { int i = (int)v; return i + (i < v); }
 static int16_t sat_short_from_float(float v)
@@ -962,5 +968,85 @@ void orc_undistort_points(const float* xy, int n, float ffx, float ffy, float fc
         const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
         xy_out[2 * i] = (float)(xx * ww);
         xy_out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+/* ---- cv::remap, INTER_LINEAR, 8-bit, float maps ------------------------------------------------------------------ */
+#define RM_TAB 32                 /* INTER_TAB_SIZE = 1 << INTER_BITS (5) */
+#define RM_SCALE 32768            /* INTER_REMAP_COEF_SCALE = 1 << 15 */
+static short rm_tab[RM_TAB * RM_TAB * 4 + 8];      /* BilinearTab_i: static, zero until filled (the sum fix-up looks past an entry) */
+static int rm_tab_ready = 0;
+
+static short rm_sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+/* initInterTab2D(INTER_LINEAR, fixpt = true) */
+static void rm_init_tab(void)
+{
+    if (rm_tab_ready) return;
+    float t1[RM_TAB * 2];
+    const float scale = 1.f / RM_TAB;
+    for (int i = 0; i < RM_TAB; ++i) { const float x = i * scale; t1[i * 2] = 1.f - x; t1[i * 2 + 1] = x; }   /* interpolateLinear */
+    const int ksize = 2;
+    short* itab = rm_tab;
+    for (int i = 0; i < RM_TAB; ++i)
+        for (int j = 0; j < RM_TAB; ++j, itab += ksize * ksize) {
+            int isum = 0;
+            for (int k1 = 0; k1 < ksize; ++k1) {
+                const float vy = t1[i * ksize + k1];
+                for (int k2 = 0; k2 < ksize; ++k2) {
+                    const float v = vy * t1[j * ksize + k2];
+                    isum += itab[k1 * ksize + k2] = rm_sat_short(orc_cv_round((double)(v * RM_SCALE)));
+                }
+            }
+            if (isum != RM_SCALE) {
+                const int diff = isum - RM_SCALE;
+                const int ksize2 = ksize / 2;
+                int Mk1 = ksize2, Mk2 = ksize2, mk1 = ksize2, mk2 = ksize2;
+                for (int k1 = ksize2; k1 < ksize2 + 2; ++k1)
+                    for (int k2 = ksize2; k2 < ksize2 + 2; ++k2) {
+                        if (itab[k1 * ksize + k2] < itab[mk1 * ksize + mk2]) { mk1 = k1; mk2 = k2; }
+                        else if (itab[k1 * ksize + k2] > itab[Mk1 * ksize + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                    }
+                if (diff < 0) itab[Mk1 * ksize + Mk2] = (short)(itab[Mk1 * ksize + Mk2] - diff);
+                else itab[mk1 * ksize + mk2] = (short)(itab[mk1 * ksize + mk2] - diff);
+            }
+        }
+    rm_tab_ready = 1;
+}
+
+void orc_remap_linear_u8(const uint8_t* src, int sw, int sh, ptrdiff_t sstride,
+                         const float* map_x, const float* map_y, ptrdiff_t map_stride,
+                         uint8_t* dst, int dw, int dh, ptrdiff_t dstride)
+{
+    rm_init_tab();
+    const unsigned width1 = (unsigned)(sw - 1 > 0 ? sw - 1 : 0), height1 = (unsigned)(sh - 1 > 0 ? sh - 1 : 0);
+    for (int dy = 0; dy < dh; ++dy) {
+        const float* sX = map_x + dy * map_stride;
+        const float* sY = map_y + dy * map_stride;
+        uint8_t* D = dst + dy * dstride;
+        for (int dx = 0; dx < dw; ++dx) {
+            /* RemapInvoker, CV_32FC1 pair of maps, bilinear */
+            const int fx = orc_cv_round((double)(sX[dx] * RM_TAB)), fy = orc_cv_round((double)(sY[dx] * RM_TAB));
+            const int v = (fy & (RM_TAB - 1)) * RM_TAB + (fx & (RM_TAB - 1));
+            const int sx = rm_sat_short(fx >> 5), sy = rm_sat_short(fy >> 5);
+            const short* w = rm_tab + v * 4;
+            int val;
+            if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+                const uint8_t* S = src + sy * sstride + sx;
+                val = S[0] * w[0] + S[1] * w[1] + S[sstride] * w[2] + S[sstride + 1] * w[3];
+            } else {
+                if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) { D[dx] = 0; continue; }       /* cval */
+                /* borderInterpolate(p, len, BORDER_CONSTANT) = p inside, -1 outside */
+                const int sx0 = (unsigned)sx < (unsigned)sw ? sx : -1, sx1 = (unsigned)(sx + 1) < (unsigned)sw ? sx + 1 : -1;
+                const int sy0 = (unsigned)sy < (unsigned)sh ? sy : -1, sy1 = (unsigned)(sy + 1) < (unsigned)sh ? sy + 1 : -1;
+                const int v0 = sx0 >= 0 && sy0 >= 0 ? src[sy0 * sstride + sx0] : 0;
+                const int v1 = sx1 >= 0 && sy0 >= 0 ? src[sy0 * sstride + sx1] : 0;
+                const int v2 = sx0 >= 0 && sy1 >= 0 ? src[sy1 * sstride + sx0] : 0;
+                const int v3 = sx1 >= 0 && sy1 >= 0 ? src[sy1 * sstride + sx1] : 0;
+                val = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+            }
+            const int r = (val + (1 << 14)) >> 15;                                                     /* FixedPtCast<int, uchar, 15> */
+            D[dx] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
     }
 }

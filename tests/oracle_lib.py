@@ -401,3 +401,15 @@ def undistort_points(xy, fx, fy, cx, cy, k1, k2, p1, p2, k3):
     out = np.zeros_like(xy)
     lib.orc_undistort_points(_ptr(xy), xy.shape[0], fx, fy, cx, cy, k1, k2, p1, p2, k3, _ptr(out))
     return out
+
+
+lib.orc_remap_linear_u8.restype = None; lib.orc_remap_linear_u8.argtypes = [_vp, _i, _i, _pd, _vp, _vp, _pd, _vp, _i, _i, _pd]
+
+
+def remap_linear_u8(src, map_x, map_y):
+    src = np.ascontiguousarray(src, np.uint8); map_x = np.ascontiguousarray(map_x, np.float32); map_y = np.ascontiguousarray(map_y, np.float32)
+    dh, dw = map_x.shape
+    out = np.zeros((dh, dw), np.uint8)
+    lib.orc_remap_linear_u8(_ptr(src), src.shape[1], src.shape[0], src.strides[0], _ptr(map_x), _ptr(map_y), map_x.strides[0] // 4,
+                            _ptr(out), dw, dh, out.strides[0])
+    return out

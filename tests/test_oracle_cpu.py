@@ -291,3 +291,23 @@ def test_undistort_points_properties(oracle):
     yd = y * cd + np.float32(p1) * (r2 + 2 * y * y) + 2 * np.float32(p2) * x * y
     back = np.stack([xd * np.float32(fx) + np.float32(cx), yd * np.float32(fy) + np.float32(cy)], 1)
     assert np.abs(back - xy).max() < 0.05
+
+
+def test_remap_known_answers(oracle):
+    """cv::remap INTER_LINEAR by hand: integer positions copy the source (weights 32767, 0, 0, 1), a half-pixel shift
+    averages with rounding up, quarter positions blend 3:1, positions outside give the constant border 0 and the last
+    row / column blend with it."""
+    src = np.array([[10, 20, 40], [50, 90, 200], [0, 255, 255]], np.uint8)
+    yy, xx = np.mgrid[0:3, 0:3].astype(np.float32)
+    assert np.array_equal(oracle.remap_linear_u8(src, xx, yy), src)
+    half = oracle.remap_linear_u8(src, xx + 0.5, yy)
+    assert list(half[0]) == [15, 30, 20] and list(half[1]) == [70, 145, 100]            # last column: half of the pixel, half border
+    quarter = oracle.remap_linear_u8(src, xx[:, :2] + 0.25, yy[:, :2] + 0.25)
+    # (0,0): 10*.5625 + 20*.1875 + 50*.1875 + 90*.0625 = 24.375 -> 24
+    assert quarter[0, 0] == 24
+    out = oracle.remap_linear_u8(src, xx - 5, yy)
+    assert not out.any()
+    edge = oracle.remap_linear_u8(src, xx - 0.5, yy)
+    assert list(edge[0]) == [5, 15, 30]                                                 # left neighbour outside: border 0
+    # rounding of the map to 1/32 pixel: 0.49 * 32 = 15.68 -> 16/32 = the half-pixel result
+    assert np.array_equal(oracle.remap_linear_u8(src, xx + np.float32(0.49), yy), half)

@@ -109,6 +109,10 @@ _SIGS = {
     "orbx_vocabulary_descend_device": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "orbx_vocabulary_transform": (_i, [_vp, _vp, _i, _i, _vp, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     "orbx_synth_vocabulary": (_i, [C.c_uint32, _i, _i, _vp, _vp, _vp, _vp]),
+    "orbx_remap_create": (_i, [_i, _vp, _vp, _pd, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "orbx_remap_destroy": (None, [_vp]),
+    "orbx_remap_batch_device": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _pd, _pd, _vp]),
+    "orbx_remap_image": (_i, [_vp, _vp, _pd, _vp, _pd]),
     "orbx_synth_frame": (None, [C.c_uint32, _i, _i, _vp, _pd]),
     "orbx_synth_stereo": (None, [C.c_uint32, _i, _i, _vp, _vp, _pd]),
     "orbx_synth_descriptors": (None, [C.c_uint32, _i64, _vp]),
@@ -496,6 +500,36 @@ def synth_vocabulary(seed, k, L):
     parent = np.zeros(n, np.int32); leaf = np.zeros(n, np.uint8); desc = np.zeros((n, 32), np.uint8); weight = np.zeros(n, np.float64)
     lib.orbx_synth_vocabulary(seed, k, L, _ptr(parent), _ptr(leaf), _ptr(desc), _ptr(weight))
     return parent, leaf, desc, weight
+
+
+class Remapper:
+    """orbx_remapper: cv::remap(INTER_LINEAR) with fixed float maps (stereo rectification)."""
+
+    def __init__(self, map_x, map_y, src_w, src_h, device=-1):
+        map_x = np.ascontiguousarray(map_x, np.float32); map_y = np.ascontiguousarray(map_y, np.float32)
+        assert map_x.shape == map_y.shape
+        self.dh, self.dw = map_x.shape
+        self.sw, self.sh = src_w, src_h
+        h = C.c_void_p()
+        _check(lib.orbx_remap_create(device, _ptr(map_x), _ptr(map_y), map_x.strides[0] // 4, self.dw, self.dh, src_w, src_h, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib.orbx_remap_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def remap(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.sh, self.sw)
+        out = np.zeros((self.dh, self.dw), np.uint8)
+        _check(lib.orbx_remap_image(self.h, _ptr(img), img.strides[0], _ptr(out), out.strides[0]))
+        return out
+
+    def remap_batch_device(self, d_src, src_row_stride, src_frame_stride, n_frames, d_dst, dst_row_stride, dst_frame_stride, stream=None):
+        _check(lib.orbx_remap_batch_device(self.h, d_src, src_row_stride, src_frame_stride, n_frames, d_dst, dst_row_stride, dst_frame_stride, stream))
 
 
 class Vocabulary:
