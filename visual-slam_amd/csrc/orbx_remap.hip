@@ -70,6 +70,18 @@ __device__ __forceinline__ uint32_t remap_pixel(const uint8_t* __restrict__ src,
     return (uint32_t)min((sum + (1 << 14)) >> 15, 255);
 }
 
+struct __attribute__((packed, aligned(1))) u64_unaligned { uint32_t x, y; };
+struct __attribute__((packed, aligned(4))) u128_aligned4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(2))) u64_aligned2 { uint32_t x, y; };
+
+__device__ __forceinline__ uint32_t blend(int v00, int v01, int v10, int v11, uint32_t f)
+{
+    const int a = (int)(f & 31), b = (int)(f >> 5);
+    int w00 = (32 - b) * (32 - a) * 32, w01 = (32 - b) * a * 32, w10 = b * (32 - a) * 32, w11 = b * a * 32;
+    if (f == 0) { w00 = 32767; w11 = 1; }
+    return (uint32_t)min((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15, 255);
+}
+
 __global__ __launch_bounds__(256) void k_remap(const uint8_t* __restrict__ src, long long src_stride, long long src_frame, int sw, int sh,
                                                const uint32_t* __restrict__ xy, const uint16_t* __restrict__ frac, int dw, int dh, int qpr,
                                                uint8_t* __restrict__ dst, long long dst_stride, long long dst_frame)
@@ -81,9 +93,42 @@ __global__ __launch_bounds__(256) void k_remap(const uint8_t* __restrict__ src, 
     uint8_t* d = dst + (long long)blockIdx.y * dst_frame + (long long)y * dst_stride + x;
     const size_t m = (size_t)y * dw + x;
     uint32_t out = 0;
+    bool done = false;
+    if (x + 4 <= dw) {
+        // smooth maps: the four pixels read one source row pair and at most eight adjacent columns, so two 8-byte loads
+        // serve all sixteen taps
+        const u128_aligned4 p = *reinterpret_cast<const u128_aligned4*>(xy + m);
+        const u64_aligned2 fr = *reinterpret_cast<const u64_aligned2*>(frac + m);
+        const uint32_t pk[4] = {p.x, p.y, p.z, p.w};
+        const uint32_t fk[4] = {fr.x & 0xFFFFu, fr.x >> 16, fr.y & 0xFFFFu, fr.y >> 16};
+        const int sy = (int)(short)(p.x >> 16), sx0 = (int)(short)(p.x & 0xFFFF);
+        bool fast = (unsigned)sy < (unsigned)max(sh - 1, 0) && sx0 >= 0 && sx0 + 8 <= sw;
+        int off[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (x + k < dw) out |= remap_pixel(s, src_stride, sw, sh, xy[m + k], frac[m + k]) << (8 * k);
+        for (int k = 0; k < 4; ++k) {
+            off[k] = (int)(short)(pk[k] & 0xFFFF) - sx0;
+            fast = fast && (int)(short)(pk[k] >> 16) == sy && (unsigned)off[k] <= 6u;
+        }
+        if (fast) {
+            const uint8_t* r0 = s + (long long)sy * src_stride + sx0;
+            const u64_unaligned a = *reinterpret_cast<const u64_unaligned*>(r0), b = *reinterpret_cast<const u64_unaligned*>(r0 + src_stride);
+            const unsigned long long ra = ((unsigned long long)a.y << 32) | a.x, rb = ((unsigned long long)b.y << 32) | b.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sh8 = 8 * off[k];
+                out |= blend((int)((ra >> sh8) & 255), (int)((ra >> (sh8 + 8)) & 255), (int)((rb >> sh8) & 255), (int)((rb >> (sh8 + 8)) & 255), fk[k]) << (8 * k);
+            }
+            done = true;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out |= remap_pixel(s, src_stride, sw, sh, pk[k], fk[k]) << (8 * k);
+            done = true;
+        }
+    }
+    if (!done) {
+        for (int k = 0; k < 4; ++k)
+            if (x + k < dw) out |= remap_pixel(s, src_stride, sw, sh, xy[m + k], frac[m + k]) << (8 * k);
+    }
     if (x + 4 <= dw && (((uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t*>(d) = out;
     else for (int k = 0; k < 4 && x + k < dw; ++k) d[k] = (uint8_t)(out >> (8 * k));
 }
