@@ -358,6 +358,20 @@ int orbx_vocabulary_transform(orbx_vocabulary* v, const uint8_t* desc, int n, in
                               uint32_t* fv_node_ids, int32_t* fv_node_ptr, int32_t* fv_features, int32_t* fv_n_nodes);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Descriptor matrices in the reference's map files                                            */
+/* ------------------------------------------------------------------------------------------ */
+/* The cv::Mat payload the reference's Boost binary archives hold for KeyFrame::mDescriptors and MapPoint::mDescriptor
+ * (save / load in include/MapPoint.h:466-501; archives opened with no_header in src/System.cc:385, 400): int cols,
+ * int rows, size_t elemSize, size_t type, then cols*rows*elemSize raw bytes, all little-endian, 24 + data bytes.
+ * Only this payload is covered: the class-tracking bytes Boost puts in front of the first cv::Mat of an archive depend
+ * on the Boost version.  Host-only helpers, no device work. */
+int64_t orbx_mat_record_bytes(int rows, int cols, int elem_size);
+/* writes the record of a continuous rows x cols matrix; returns the bytes written or -1 when cap is too small */
+int64_t orbx_mat_record_write(const uint8_t* data, int rows, int cols, int elem_size, int elem_type, uint8_t* out, int64_t cap);
+/* parses a record; *data points into rec.  Returns the record's length or -1 for a truncated / inconsistent record */
+int64_t orbx_mat_record_read(const uint8_t* rec, int64_t len, int* rows, int* cols, int* elem_size, int* elem_type, const uint8_t** data);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Synthetic inputs for benchmarks and tests (no counterpart in the reference)                 */
 /* ------------------------------------------------------------------------------------------ */
 /* Frame generator: PCG32 seeded 0x5EED0000 + frame_index; W*H/200 random rectangles (side 6..48,

@@ -103,3 +103,22 @@ def test_best2_merge_host(vsa, oracle):
         merged = vsa.best2_merge(np.stack(parts))
         for f in ("best", "best_idx", "second"):
             assert np.array_equal(merged[f], whole[f]), (shards, f)
+
+
+def test_mat_record_layout(vsa):
+    """The cv::Mat payload of the reference's map files (include/MapPoint.h:466-501): cols, rows as int32, elemSize and
+    type as 64-bit, then the bytes."""
+    desc = (np.arange(3 * 32, dtype=np.uint32) * 7 % 256).astype(np.uint8).reshape(3, 32)
+    rec = vsa.mat_record_write(desc)
+    assert len(rec) == 24 + 96
+    assert rec[:24] == (32).to_bytes(4, "little") + (3).to_bytes(4, "little") + (1).to_bytes(8, "little") + (0).to_bytes(8, "little")
+    assert rec[24:] == desc.tobytes()
+    back, es, et, n = vsa.mat_record_read(rec + b"trailing")
+    assert n == len(rec) and es == 1 and et == 0 and np.array_equal(back, desc)
+    pose = np.arange(16, dtype=np.float32).reshape(4, 4)                      # a CV_32F matrix (type code 5), e.g. a pose
+    back, es, et, _ = vsa.mat_record_read(vsa.mat_record_write(pose, elem_type=5))
+    assert es == 4 and et == 5 and np.array_equal(back.view(np.float32), pose)
+    with pytest.raises(ValueError):
+        vsa.mat_record_read(rec[:50])
+    empty, _, _, n0 = vsa.mat_record_read(vsa.mat_record_write(np.zeros((0, 32), np.uint8)))
+    assert n0 == 24 and empty.shape == (0, 32)

@@ -113,6 +113,9 @@ _SIGS = {
     "orbx_remap_destroy": (None, [_vp]),
     "orbx_remap_batch_device": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _pd, _pd, _vp]),
     "orbx_remap_image": (_i, [_vp, _vp, _pd, _vp, _pd]),
+    "orbx_mat_record_bytes": (_i64, [_i, _i, _i]),
+    "orbx_mat_record_write": (_i64, [_vp, _i, _i, _i, _i, _vp, _i64]),
+    "orbx_mat_record_read": (_i64, [_vp, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
     "orbx_synth_frame": (None, [C.c_uint32, _i, _i, _vp, _pd]),
     "orbx_synth_stereo": (None, [C.c_uint32, _i, _i, _vp, _vp, _pd]),
     "orbx_synth_descriptors": (None, [C.c_uint32, _i64, _vp]),
@@ -500,6 +503,28 @@ def synth_vocabulary(seed, k, L):
     parent = np.zeros(n, np.int32); leaf = np.zeros(n, np.uint8); desc = np.zeros((n, 32), np.uint8); weight = np.zeros(n, np.float64)
     lib.orbx_synth_vocabulary(seed, k, L, _ptr(parent), _ptr(leaf), _ptr(desc), _ptr(weight))
     return parent, leaf, desc, weight
+
+
+def mat_record_write(mat, elem_type=0):
+    """The cv::Mat payload of the reference's map archives for a 2-D array (elem_type: the OpenCV type code, CV_8U = 0)."""
+    mat = np.ascontiguousarray(mat)
+    rows, cols = mat.shape
+    out = np.zeros(lib.orbx_mat_record_bytes(rows, cols, mat.itemsize), np.uint8)
+    n = lib.orbx_mat_record_write(_ptr(mat.view(np.uint8)) if mat.size else None, rows, cols, mat.itemsize, elem_type, _ptr(out), len(out))
+    if n != len(out):
+        raise ValueError("record not written")
+    return out.tobytes()
+
+
+def mat_record_read(buf):
+    """Returns (array of raw bytes rows x (cols*elem_size), elem_size, elem_type, record length)."""
+    raw = np.frombuffer(buf, np.uint8)
+    rows, cols, es, et = _i(), _i(), _i(), _i()
+    data = C.c_void_p()
+    n = lib.orbx_mat_record_read(_ptr(raw), len(raw), C.byref(rows), C.byref(cols), C.byref(es), C.byref(et), C.byref(data))
+    if n < 0:
+        raise ValueError("truncated or inconsistent record")
+    return raw[24:n].reshape(rows.value, cols.value * es.value).copy(), es.value, et.value, n
 
 
 class Remapper:

@@ -493,6 +493,39 @@ void orbx_synth_queries(uint32_t seed, const uint8_t* map, int64_t n_map, int nq
     }
 }
 
+int64_t orbx_mat_record_bytes(int rows, int cols, int elem_size)
+{
+    if (rows < 0 || cols < 0 || elem_size < 1) return -1;
+    return 24 + (int64_t)rows * cols * elem_size;
+}
+
+int64_t orbx_mat_record_write(const uint8_t* data, int rows, int cols, int elem_size, int elem_type, uint8_t* out, int64_t cap)
+{
+    const int64_t need = orbx_mat_record_bytes(rows, cols, elem_size);
+    if (need < 0 || !out || cap < need || (need > 24 && !data)) return -1;
+    const int32_t c = cols, r = rows;
+    const uint64_t es = (uint64_t)elem_size, et = (uint64_t)elem_type;          // size_t of the LP64 builds the reference targets
+    std::memcpy(out, &c, 4); std::memcpy(out + 4, &r, 4); std::memcpy(out + 8, &es, 8); std::memcpy(out + 16, &et, 8);
+    if (need > 24) std::memcpy(out + 24, data, (size_t)(need - 24));
+    return need;
+}
+
+int64_t orbx_mat_record_read(const uint8_t* rec, int64_t len, int* rows, int* cols, int* elem_size, int* elem_type, const uint8_t** data)
+{
+    if (!rec || len < 24) return -1;
+    int32_t c, r; uint64_t es, et;
+    std::memcpy(&c, rec, 4); std::memcpy(&r, rec + 4, 4); std::memcpy(&es, rec + 8, 8); std::memcpy(&et, rec + 16, 8);
+    if (c < 0 || r < 0 || es < 1 || es > 64 || et > 0x7FFFFFFFu) return -1;
+    const int64_t need = 24 + (int64_t)r * c * (int64_t)es;
+    if (len < need) return -1;
+    if (rows) *rows = r;
+    if (cols) *cols = c;
+    if (elem_size) *elem_size = (int)es;
+    if (elem_type) *elem_type = (int)et;
+    if (data) *data = rec + 24;
+    return need;
+}
+
 int orbx_synth_vocabulary(uint32_t seed, int k, int L, int32_t* parent, uint8_t* is_leaf, uint8_t* descriptors, double* weight)
 {
     if (k < 2 || k > 20 || L < 1 || L > 10) return -1;
