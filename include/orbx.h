@@ -227,6 +227,30 @@ int orbx_search_by_projection_keyframe(orbx_matcher* m,
                                        const orbx_keypoint* k2, const uint8_t* d2, int n2,
                                        float minX, float maxX, float minY, float maxY, int32_t* claimed, int* nmatches);
 
+/* The candidate loop that ORBmatcher::Fuse (both forms, src/ORBmatcher.cc:893-952 and :1052-1082) runs per projected
+ * map point: the key-frame features within qradius of (qu, qv) at level qlevel-1..qlevel, nearest descriptor wins (first
+ * on ties).  With qur != NULL the reprojection test of Fuse(pKF, vpMapPoints, th) is applied first (:917-941: squared
+ * error times inv_level_sigma2[octave] above 7.8 with a right coordinate, 5.99 without).  best_idx[i] = feature or -1,
+ * best_dist[i] = its distance or INT_MAX; the caller accepts <= TH_LOW and does the map-point bookkeeping (:955-974). */
+int orbx_project_best1(orbx_matcher* m,
+                       const float* qu, const float* qv, const float* qradius, const int32_t* qlevel,
+                       const uint8_t* qdesc, int nq,
+                       const orbx_keypoint* k2, const uint8_t* d2, int n2,
+                       float minX, float maxX, float minY, float maxY,
+                       const float* qur, const float* uright2, const float* inv_level_sigma2, int nlevels,
+                       int32_t* best_idx, int32_t* best_dist);
+
+/* ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1105-1329), candidate loops and agreement: feature i1 of key frame 1 with
+ * valid1[i1] (has a good map point, not matched yet, projection into key frame 2 passed the depth / image / distance tests,
+ * :1153-1186) searches key frame 2 around (u1in2, v1in2) within radius1 at level1-1..level1 with its map point's descriptor
+ * mpdesc1 (best-1, accepted <= TH_HIGH); the same from key frame 2 into 1; match12[i1] = i2 where both agree, else -1. */
+int orbx_search_by_sim3(orbx_matcher* m,
+                        const uint8_t* valid1, const float* u1in2, const float* v1in2, const float* radius1, const int32_t* level1,
+                        const uint8_t* mpdesc1, const orbx_keypoint* k1, const uint8_t* d1, int n1,
+                        const uint8_t* valid2, const float* u2in1, const float* v2in1, const float* radius2, const int32_t* level2,
+                        const uint8_t* mpdesc2, const orbx_keypoint* k2, const uint8_t* d2, int n2,
+                        float minX, float maxX, float minY, float maxY, int32_t* match12, int* nfound);
+
 /* A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) flattened: node ids ascending, the feature
  * indices of node k in features[node_ptr[k] .. node_ptr[k+1]) in their list order. */
 typedef struct orbx_feature_vector {

@@ -127,6 +127,18 @@ int   orc_search_by_projection_keyframe(const float* qu, const float* qv, const 
                                         const uint8_t* qdesc, int nq, const orc_keypoint* k2, const uint8_t* d2, int n2,
                                         float minX, float maxX, float minY, float maxY, int32_t* claimed);
 
+/* Candidate loop of ORBmatcher::Fuse, src/ORBmatcher.cc:893-952 (reproj 1) and :1052-1082 (reproj 0) */
+void  orc_fuse_candidates(const float* qu, const float* qv, const float* qur, const float* qradius, const int32_t* qlevel,
+                          const uint8_t* qdesc, int nq, const orc_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
+                          const float* inv_level_sigma2, float minX, float maxX, float minY, float maxY, int reproj,
+                          int32_t* best_idx, int32_t* best_dist);
+/* ORBmatcher::SearchBySim3 candidate loops and agreement, src/ORBmatcher.cc:1147-1328 */
+int   orc_search_by_sim3(const uint8_t* valid1, const float* u1in2, const float* v1in2, const float* radius1, const int32_t* level1,
+                         const uint8_t* mpdesc1, const orc_keypoint* k1, const uint8_t* d1, int n1,
+                         const uint8_t* valid2, const float* u2in1, const float* v2in1, const float* radius2, const int32_t* level2,
+                         const uint8_t* mpdesc2, const orc_keypoint* k2, const uint8_t* d2, int n2,
+                         float minX, float maxX, float minY, float maxY, int32_t* match12);
+
 /* DBoW2::FeatureVector flattened: node ids ascending; features of node k at features[node_ptr[k]..node_ptr[k+1]). */
 typedef struct orc_feature_vector {
     const uint32_t* node_ids; const int32_t* node_ptr; const int32_t* features; int32_t n_nodes;

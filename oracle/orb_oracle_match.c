@@ -523,3 +523,94 @@ int orc_search_by_projection_keyframe(const float* qu, const float* qv, const fl
     orc_grid_destroy(g);
     return nmatches;
 }
+
+/* Candidate loop of ORBmatcher::Fuse: src/ORBmatcher.cc:893-952 (reproj = 1: the chi-square tests :917-941, bestDist
+ * starts at 256) and :1052-1082 (reproj = 0: bestDist starts at INT_MAX).  best_dist[i] = INT_MAX when no candidate passed. */
+void orc_fuse_candidates(const float* qu, const float* qv, const float* qur, const float* qradius, const int32_t* qlevel,
+                         const uint8_t* qdesc, int nq, const orc_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
+                         const float* inv_level_sigma2, float minX, float maxX, float minY, float maxY, int reproj,
+                         int32_t* best_idx, int32_t* best_dist)
+{
+    orc_frame_grid* g = orc_grid_create(k2, n2, minX, maxX, minY, maxY);
+    int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n2 + 1));
+    for (int i = 0; i < nq; ++i) {
+        best_idx[i] = -1; best_dist[i] = INT_MAX;
+        const float u = qu[i], v = qv[i];
+        const int nPredictedLevel = qlevel[i];
+        const int nc = orc_grid_features_in_area(g, u, v, qradius[i], 0, -1, vIndices, n2);        /* KeyFrame::GetFeaturesInArea */
+        if (nc == 0) continue;
+        int bestDist = reproj ? 256 : INT_MAX, bestIdx = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int idx = vIndices[c];
+            const orc_keypoint* kp = &k2[idx];
+            const int kpLevel = kp->octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (reproj) {
+                if (uright2[idx] >= 0) {
+                    const float ex = u - kp->x, ey = v - kp->y, er = qur[i] - uright2[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u - kp->x, ey = v - kp->y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = orc_descriptor_distance(qdesc + (size_t)i * 32, d2 + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestIdx >= 0) { best_idx[i] = bestIdx; best_dist[i] = bestDist; }
+    }
+    free(vIndices);
+    orc_grid_destroy(g);
+}
+
+/* one direction of SearchBySim3, src/ORBmatcher.cc:1188-1228 */
+static void sim3_direction(const uint8_t* valid, const float* qu, const float* qv, const float* qradius, const int32_t* qlevel,
+                           const uint8_t* qdesc, int nq, const orc_keypoint* kt, const uint8_t* dt, int nt,
+                           float minX, float maxX, float minY, float maxY, int32_t* vnMatch)
+{
+    orc_frame_grid* g = orc_grid_create(kt, nt, minX, maxX, minY, maxY);
+    int32_t* vIndices = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nt + 1));
+    for (int i = 0; i < nq; ++i) {
+        vnMatch[i] = -1;
+        if (!valid[i]) continue;
+        const int nPredictedLevel = qlevel[i];
+        const int nc = orc_grid_features_in_area(g, qu[i], qv[i], qradius[i], 0, -1, vIndices, nt);
+        if (nc == 0) continue;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int idx = vIndices[c];
+            if (kt[idx].octave < nPredictedLevel - 1 || kt[idx].octave > nPredictedLevel) continue;
+            const int dist = orc_descriptor_distance(qdesc + (size_t)i * 32, dt + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+    }
+    free(vIndices);
+    orc_grid_destroy(g);
+}
+
+/* ORBmatcher::SearchBySim3 candidate loops and agreement, src/ORBmatcher.cc:1147-1328.  Returns nFound. */
+int orc_search_by_sim3(const uint8_t* valid1, const float* u1in2, const float* v1in2, const float* radius1, const int32_t* level1,
+                       const uint8_t* mpdesc1, const orc_keypoint* k1, const uint8_t* d1, int n1,
+                       const uint8_t* valid2, const float* u2in1, const float* v2in1, const float* radius2, const int32_t* level2,
+                       const uint8_t* mpdesc2, const orc_keypoint* k2, const uint8_t* d2, int n2,
+                       float minX, float maxX, float minY, float maxY, int32_t* match12)
+{
+    int32_t* vnMatch1 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n1 + 1));
+    int32_t* vnMatch2 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n2 + 1));
+    sim3_direction(valid1, u1in2, v1in2, radius1, level1, mpdesc1, n1, k2, d2, n2, minX, maxX, minY, maxY, vnMatch1);
+    sim3_direction(valid2, u2in1, v2in1, radius2, level2, mpdesc2, n2, k1, d1, n1, minX, maxX, minY, maxY, vnMatch2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        match12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { match12[i1] = idx2; nFound++; }
+        }
+    }
+    free(vnMatch1); free(vnMatch2);
+    return nFound;
+}

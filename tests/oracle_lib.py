@@ -413,3 +413,34 @@ def remap_linear_u8(src, map_x, map_y):
     lib.orc_remap_linear_u8(_ptr(src), src.shape[1], src.shape[0], src.strides[0], _ptr(map_x), _ptr(map_y), map_x.strides[0] // 4,
                             _ptr(out), dw, dh, out.strides[0])
     return out
+
+
+lib.orc_fuse_candidates.restype = None
+lib.orc_fuse_candidates.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _i, _vp, _vp]
+lib.orc_search_by_sim3.restype = _i
+lib.orc_search_by_sim3.argtypes = [_vp] * 8 + [_i] + [_vp] * 8 + [_i, _f, _f, _f, _f, _vp]
+
+
+def fuse_candidates(qu, qv, qradius, qlevel, qdesc, k2, d2, bounds, qur=None, uright2=None, inv_level_sigma2=None):
+    f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+    qu, qv, qradius, qur, uright2, inv_level_sigma2 = f32(qu), f32(qv), f32(qradius), f32(qur), f32(uright2), f32(inv_level_sigma2)
+    qlevel = np.ascontiguousarray(qlevel, np.int32); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE); d2 = np.ascontiguousarray(d2, np.uint8)
+    bi = np.zeros(len(qu), np.int32); bd = np.zeros(len(qu), np.int32)
+    lib.orc_fuse_candidates(_ptr(qu), _ptr(qv), _ptr(qur), _ptr(qradius), _ptr(qlevel), _ptr(qdesc), len(qu), _ptr(k2), _ptr(d2), _ptr(uright2),
+                            len(k2), _ptr(inv_level_sigma2), bounds[0], bounds[1], bounds[2], bounds[3], 0 if qur is None else 1, _ptr(bi), _ptr(bd))
+    return bi, bd
+
+
+def search_by_sim3(side1, k1, d1, side2, k2, d2, bounds):
+    def prep(side):
+        valid, u, v, r, lvl, desc = side
+        return (np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32),
+                np.ascontiguousarray(r, np.float32), np.ascontiguousarray(lvl, np.int32), np.ascontiguousarray(desc, np.uint8))
+    a, b = prep(side1), prep(side2)
+    k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    m12 = np.zeros(len(k1), np.int32)
+    n = lib.orc_search_by_sim3(*[_ptr(x) for x in a], _ptr(k1), _ptr(d1), len(k1), *[_ptr(x) for x in b], _ptr(k2), _ptr(d2), len(k2),
+                               bounds[0], bounds[1], bounds[2], bounds[3], _ptr(m12))
+    return m12, n

@@ -270,3 +270,50 @@ def test_search_by_projection_keyframe(vsa, oracle, matcher, motion_features):
     g = matcher.search_by_projection_keyframe(qu, qv, qradius, qlevel, d1[sel], k2, d2, (0.0, float(w), 0.0, float(h)), claimed)
     o = oracle.search_by_projection_keyframe(qu, qv, qradius, qlevel, d1[sel], k2, d2, (0.0, float(w), 0.0, float(h)), claimed)
     assert g[1] == o[1] and np.array_equal(g[0], o[0]) and g[1] > 100
+
+
+@pytest.mark.parametrize("reproj", [False, True])
+def test_fuse_candidate_loop(vsa, oracle, matcher, motion_features, reproj):
+    """ORBmatcher::Fuse, both forms: per projected map point the nearest key-frame feature in the radius and level band,
+    with the chi-square reprojection test of the local-mapping form."""
+    w, h, k1, d1, k2, d2 = motion_features
+    rng = np.random.default_rng(21 + reproj)
+    sel = rng.permutation(len(k1))[:1500]
+    tabs = vsa.scale_tables(vsa.make_params(2000))
+    qu = k1["x"][sel] + 5.0 + rng.normal(0, 1.5, len(sel)).astype(np.float32)
+    qv = k1["y"][sel] + 3.0 + rng.normal(0, 1.5, len(sel)).astype(np.float32)
+    qlevel = np.clip(k1["octave"][sel] + rng.integers(0, 2, len(sel)), 0, 7).astype(np.int32)
+    qradius = (3.0 * tabs["scale"][qlevel]).astype(np.float32)
+    bounds = (0.0, float(w), 0.0, float(h))
+    if reproj:
+        uright2 = np.where(rng.random(len(k2)) < 0.6, k2["x"] - rng.uniform(2, 30, len(k2)), -1).astype(np.float32)
+        qur = (qu - rng.uniform(2, 30, len(sel))).astype(np.float32)
+        g = matcher.project_best1(qu, qv, qradius, qlevel, d1[sel], k2, d2, bounds, qur, uright2, tabs["inv_sigma2"])
+        o = oracle.fuse_candidates(qu, qv, qradius, qlevel, d1[sel], k2, d2, bounds, qur, uright2, tabs["inv_sigma2"])
+    else:
+        g = matcher.project_best1(qu, qv, qradius, qlevel, d1[sel], k2, d2, bounds)
+        o = oracle.fuse_candidates(qu, qv, qradius, qlevel, d1[sel], k2, d2, bounds)
+    assert np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+    assert np.count_nonzero(g[0] >= 0) > 200 and np.count_nonzero(g[0] < 0) > 20
+    assert np.count_nonzero(g[1][g[0] >= 0] <= 50) > 100            # fused at TH_LOW
+
+
+def test_search_by_sim3(vsa, oracle, matcher, motion_features):
+    """ORBmatcher::SearchBySim3: both projection directions, best-1 within TH_HIGH, mutual agreement."""
+    w, h, k1, d1, k2, d2 = motion_features
+    rng = np.random.default_rng(31)
+    scale = vsa.scale_tables(vsa.make_params(2000))["scale"]
+
+    def side(ks, ds, dx, dy):
+        n = len(ks)
+        valid = (rng.random(n) < 0.8).astype(np.uint8)
+        u = ks["x"] + dx + rng.normal(0, 1.0, n).astype(np.float32); v = ks["y"] + dy + rng.normal(0, 1.0, n).astype(np.float32)
+        lvl = np.clip(ks["octave"] + rng.integers(0, 2, n), 0, 7).astype(np.int32)
+        flips = np.packbits(rng.random((n, 256)) < 0.03, axis=1)                     # the map point's descriptor is not the feature's own
+        return valid, u, v, (7.5 * scale[lvl]).astype(np.float32), lvl, ds ^ flips
+
+    s1, s2 = side(k1, d1, 5.0, 3.0), side(k2, d2, -5.0, -3.0)
+    bounds = (0.0, float(w), 0.0, float(h))
+    g = matcher.search_by_sim3(s1, k1, d1, s2, k2, d2, bounds)
+    o = oracle.search_by_sim3(s1, k1, d1, s2, k2, d2, bounds)
+    assert g[1] == o[1] and np.array_equal(g[0], o[0]) and g[1] > 200

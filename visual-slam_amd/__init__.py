@@ -72,6 +72,8 @@ _SIGS = {
     "orbx_pyramid_level_device": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd)]),
     "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _pd]),
     "orbx_search_by_projection_keyframe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, C.POINTER(_i)]),
+    "orbx_project_best1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _i, _vp, _vp]),
+    "orbx_search_by_sim3": (_i, [_vp] + [_vp] * 8 + [_i] + [_vp] * 8 + [_i, _f, _f, _f, _f, _vp, C.POINTER(_i)]),
     "orbx_search_by_bow": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "orbx_search_for_triangulation": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp,
                                            _i, _i, _i, _vp, C.POINTER(_i)]),
@@ -421,6 +423,32 @@ class Matcher:
                                                       _ptr(k2), _ptr(d2), len(k2), bounds[0], bounds[1], bounds[2], bounds[3],
                                                       _ptr(claimed), C.byref(n)))
         return claimed, n.value
+
+    def project_best1(self, qu, qv, qradius, qlevel, qdesc, k2, d2, bounds, qur=None, uright2=None, inv_level_sigma2=None):
+        """Candidate loop of ORBmatcher::Fuse; qur given = the reprojection test of the local-mapping form."""
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+        qu, qv, qradius, qur, uright2, inv_level_sigma2 = f32(qu), f32(qv), f32(qradius), f32(qur), f32(uright2), f32(inv_level_sigma2)
+        qlevel = np.ascontiguousarray(qlevel, np.int32); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE); d2 = np.ascontiguousarray(d2, np.uint8)
+        bi = np.zeros(len(qu), np.int32); bd = np.zeros(len(qu), np.int32)
+        _check(lib.orbx_project_best1(self.h, _ptr(qu), _ptr(qv), _ptr(qradius), _ptr(qlevel), _ptr(qdesc), len(qu), _ptr(k2), _ptr(d2), len(k2),
+                                      bounds[0], bounds[1], bounds[2], bounds[3], _ptr(qur), _ptr(uright2), _ptr(inv_level_sigma2),
+                                      0 if inv_level_sigma2 is None else len(inv_level_sigma2), _ptr(bi), _ptr(bd)))
+        return bi, bd
+
+    def search_by_sim3(self, side1, k1, d1, side2, k2, d2, bounds):
+        """side = (valid, u, v, radius, level, map-point descriptors) of each key frame's features projected into the other."""
+        def prep(side):
+            valid, u, v, r, lvl, desc = side
+            return (np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32),
+                    np.ascontiguousarray(r, np.float32), np.ascontiguousarray(lvl, np.int32), np.ascontiguousarray(desc, np.uint8))
+        a, b = prep(side1), prep(side2)
+        k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        m12 = np.zeros(len(k1), np.int32); n = C.c_int()
+        _check(lib.orbx_search_by_sim3(self.h, *[_ptr(x) for x in a], _ptr(k1), _ptr(d1), len(k1), *[_ptr(x) for x in b], _ptr(k2), _ptr(d2),
+                                       len(k2), bounds[0], bounds[1], bounds[2], bounds[3], _ptr(m12), C.byref(n)))
+        return m12, n.value
 
     def search_by_bow(self, d1, angle1, eligible1, nodes1, d2, angle2, eligible2, nodes2, nnratio=0.7, check_ori=True, keyframe_form=0):
         d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)

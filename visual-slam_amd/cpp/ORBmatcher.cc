@@ -185,6 +185,39 @@ int ORBmatcher::SearchByProjectionKeyFrame(const FrameView& KF, const std::vecto
     return nmatches;
 }
 
+void ORBmatcher::FuseCandidates(const FrameView& KF, const std::vector<ProjectedQuery>& vQueries, bool bCheckReprojection,
+                                const std::vector<float>& vInvLevelSigma2, std::vector<int>& vnBestIdx, std::vector<int>& vnBestDist)
+{
+    const int n2 = (int)KF.keysUn->size(), nq = (int)vQueries.size();
+    vnBestIdx.assign(nq, -1); vnBestDist.assign(nq, 0x7FFFFFFF);
+    if (nq == 0 || n2 == 0) return;
+    if (bCheckReprojection && !KF.uRight) throw std::runtime_error("FuseCandidates: the reprojection test needs mvuRight");
+    QueryArrays q(vQueries);
+    std::vector<unsigned char> d2 = packed_rows(*KF.descriptors);
+    check(orbx_project_best1(Context(), q.u.data(), q.v.data(), q.r.data(), q.level.data(), q.desc.data(), nq, as_orbx(*KF.keysUn), d2.data(), n2,
+                             KF.minX, KF.maxX, KF.minY, KF.maxY, bCheckReprojection ? q.ur.data() : nullptr,
+                             bCheckReprojection ? KF.uRight->data() : nullptr, bCheckReprojection ? vInvLevelSigma2.data() : nullptr,
+                             (int)vInvLevelSigma2.size(), vnBestIdx.data(), vnBestDist.data()), "Fuse");
+}
+
+int ORBmatcher::SearchBySim3(const FrameView& KF1, const std::vector<ProjectedQuery>& vQueries1, const std::vector<bool>& vbValid1,
+                             const FrameView& KF2, const std::vector<ProjectedQuery>& vQueries2, const std::vector<bool>& vbValid2,
+                             std::vector<int>& vnMatches12)
+{
+    const int n1 = (int)KF1.keysUn->size(), n2 = (int)KF2.keysUn->size();
+    if ((int)vQueries1.size() != n1 || (int)vQueries2.size() != n2) throw std::runtime_error("SearchBySim3: one query per feature");
+    vnMatches12.assign(n1, -1);
+    if (n1 == 0 || n2 == 0) return 0;
+    QueryArrays q1(vQueries1), q2(vQueries2);
+    std::vector<unsigned char> d1 = packed_rows(*KF1.descriptors), d2 = packed_rows(*KF2.descriptors), f1 = flags(vbValid1, n1), f2 = flags(vbValid2, n2);
+    int nFound = 0;
+    check(orbx_search_by_sim3(Context(), f1.data(), q1.u.data(), q1.v.data(), q1.r.data(), q1.level.data(), q1.desc.data(), as_orbx(*KF1.keysUn),
+                              d1.data(), n1, f2.data(), q2.u.data(), q2.v.data(), q2.r.data(), q2.level.data(), q2.desc.data(),
+                              as_orbx(*KF2.keysUn), d2.data(), n2, KF2.minX, KF2.maxX, KF2.minY, KF2.maxY, vnMatches12.data(), &nFound),
+          "SearchBySim3");
+    return nFound;
+}
+
 int ORBmatcher::SearchByBoW(const FrameView& KF, const std::vector<bool>& vbGoodMapPointKF, const FeatureVectorMap& vFeatVecKF,
                             const FrameView& F, const std::vector<cv::KeyPoint>& vKeysF, const FeatureVectorMap& vFeatVecF,
                             std::vector<int>& vnMatchesF)

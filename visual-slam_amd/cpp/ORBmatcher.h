@@ -68,6 +68,21 @@ public:
     // uRight and angle are not used.  vnClaimed as above.
     int SearchByProjectionKeyFrame(const FrameView& KF, const std::vector<ProjectedQuery>& vQueries, std::vector<int>& vnClaimed);
 
+    // The candidate loop of both Fuse forms (src/ORBmatcher.cc:893-952 and :1052-1082): per projected map point (u, v,
+    // radius = th * scale[level], level, descriptor; uRight = the projected right coordinate, :873) the nearest feature of
+    // the key frame within the radius at level-1..level.  bCheckReprojection applies the chi-square test of
+    // Fuse(pKF, vpMapPoints, th) (:917-941; needs KF.uRight and vInvLevelSigma2).  vnBestIdx[i] = -1 when none;
+    // the caller accepts vnBestDist[i] <= TH_LOW and replaces / adds map points (:955-974, :1085-1099).
+    void FuseCandidates(const FrameView& KF, const std::vector<ProjectedQuery>& vQueries, bool bCheckReprojection,
+                        const std::vector<float>& vInvLevelSigma2, std::vector<int>& vnBestIdx, std::vector<int>& vnBestDist);
+
+    // src/ORBmatcher.cc:1105-1329, SearchBySim3: vQueries1[i1] = feature i1 of key frame 1 projected into key frame 2 (descriptor =
+    // its map point's), vbValid1[i1] = passed the tests of :1153-1186; likewise 2 into 1.  vnMatches12[i1] = feature of key frame 2
+    // (the reference stores its map point in vpMatches12[i1], :1322) or -1.  Returns nFound.
+    int SearchBySim3(const FrameView& KF1, const std::vector<ProjectedQuery>& vQueries1, const std::vector<bool>& vbValid1,
+                     const FrameView& KF2, const std::vector<ProjectedQuery>& vQueries2, const std::vector<bool>& vbValid2,
+                     std::vector<int>& vnMatches12);
+
     // src/ORBmatcher.cc:159-291, SearchByBoW(KeyFrame*, Frame&, ...).  vbGoodMapPointKF[i]: key-frame feature i has a map
     // point that is not bad; vKeysF = F.mvKeys (the reference takes the frame's angles from there, :241).
     // vnMatchesF[iF] = key-frame feature whose map point the reference stores in vpMapPointMatches[iF], or -1.

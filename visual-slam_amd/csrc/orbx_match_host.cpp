@@ -279,6 +279,104 @@ struct BowRows {
 
 } // namespace
 
+// Shared candidate loop of ORBmatcher::Fuse (src/ORBmatcher.cc:893-952, :1052-1082) and SearchBySim3 (:1192-1222, :1272-1302)
+static int project_best1(orbx_matcher* m, const float* qu, const float* qv, const float* qradius, const int32_t* qlevel, const uint8_t* qdesc,
+                         const uint8_t* qvalid, int nq, const orbx_keypoint* k2, const uint8_t* d2, int n2,
+                         float minX, float maxX, float minY, float maxY,
+                         const float* qur, const float* uright2, const float* inv_level_sigma2,
+                         int32_t* best_idx, int32_t* best_dist)
+{
+    FrameGrid grid;
+    grid.build(k2, n2, minX, maxX, minY, maxY);
+    Csr csr;
+    csr.start(nq);
+    std::vector<int> v;
+    for (int i = 0; i < nq; ++i) {
+        v.clear();
+        if (!qvalid || qvalid[i]) grid.query(qu[i], qv[i], qradius[i], qlevel[i] - 1, qlevel[i], v);   // GetFeaturesInArea + the level test
+        csr.push_row(v);
+    }
+    int rc = csr.run(m, qdesc, nq, d2, n2);
+    if (rc) return rc;
+    for (int i = 0; i < nq; ++i) {
+        int bestDist = 0x7FFFFFFF, bestIdx = -1;
+        for (int c = csr.rowptr[i]; c < csr.rowptr[i + 1]; ++c) {
+            const int idx = csr.cand[c];
+            if (qur) {                                           // reprojection test of Fuse(pKF, vpMapPoints, th), :917-941
+                const orbx_keypoint& kp = k2[idx];
+                const float ex = qu[i] - kp.x, ey = qv[i] - kp.y;
+                if (uright2[idx] >= 0) {
+                    const float er = qur[i] - uright2[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kp.octave] > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kp.octave] > 5.99) continue;
+                }
+            }
+            if (csr.dist[c] < bestDist) { bestDist = csr.dist[c]; bestIdx = idx; }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist;
+    }
+    return ORBX_OK;
+}
+
+extern "C" {
+
+int orbx_project_best1(orbx_matcher* m, const float* qu, const float* qv, const float* qradius, const int32_t* qlevel,
+                       const uint8_t* qdesc, int nq, const orbx_keypoint* k2, const uint8_t* d2, int n2,
+                       float minX, float maxX, float minY, float maxY,
+                       const float* qur, const float* uright2, const float* inv_level_sigma2, int nlevels,
+                       int32_t* best_idx, int32_t* best_dist)
+{
+    if (!m || nq < 0 || n2 < 0 || !(maxX > minX) || !(maxY > minY)) { set_error("orbx_project_best1: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (nq == 0) return ORBX_OK;
+    if (!best_idx || !best_dist) { set_error("orbx_project_best1: null pointer"); return ORBX_ERR_BAD_ARG; }
+    for (int i = 0; i < nq; ++i) { best_idx[i] = -1; best_dist[i] = 0x7FFFFFFF; }
+    if (n2 == 0) return ORBX_OK;
+    if (!qu || !qv || !qradius || !qlevel || !qdesc || !k2 || !d2) { set_error("orbx_project_best1: null pointer"); return ORBX_ERR_BAD_ARG; }
+    if (qur && (!uright2 || !inv_level_sigma2 || nlevels < 1 || nlevels > kMaxLevels)) { set_error("orbx_project_best1: the reprojection test needs uright2 and inv_level_sigma2"); return ORBX_ERR_BAD_ARG; }
+    if (!octaves_ok(k2, n2)) { set_error("octave out of range"); return ORBX_ERR_BAD_ARG; }
+    if (qur) for (int i = 0; i < n2; ++i) if (k2[i].octave >= nlevels) { set_error("octave outside inv_level_sigma2"); return ORBX_ERR_BAD_ARG; }
+    return project_best1(m, qu, qv, qradius, qlevel, qdesc, nullptr, nq, k2, d2, n2, minX, maxX, minY, maxY, qur, uright2, inv_level_sigma2,
+                         best_idx, best_dist);
+}
+
+int orbx_search_by_sim3(orbx_matcher* m,
+                        const uint8_t* valid1, const float* u1in2, const float* v1in2, const float* radius1, const int32_t* level1,
+                        const uint8_t* mpdesc1, const orbx_keypoint* k1, const uint8_t* d1, int n1,
+                        const uint8_t* valid2, const float* u2in1, const float* v2in1, const float* radius2, const int32_t* level2,
+                        const uint8_t* mpdesc2, const orbx_keypoint* k2, const uint8_t* d2, int n2,
+                        float minX, float maxX, float minY, float maxY, int32_t* match12, int* nfound)
+{
+    if (!m || !nfound || n1 < 0 || n2 < 0 || !(maxX > minX) || !(maxY > minY)) { set_error("orbx_search_by_sim3: bad argument"); return ORBX_ERR_BAD_ARG; }
+    *nfound = 0;
+    if (n1 > 0 && !match12) { set_error("orbx_search_by_sim3: null pointer"); return ORBX_ERR_BAD_ARG; }
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    if (!valid1 || !u1in2 || !v1in2 || !radius1 || !level1 || !mpdesc1 || !k1 || !d1 || !valid2 || !u2in1 || !v2in1 || !radius2 || !level2 ||
+        !mpdesc2 || !k2 || !d2) { set_error("orbx_search_by_sim3: null pointer"); return ORBX_ERR_BAD_ARG; }
+    if (!octaves_ok(k1, n1) || !octaves_ok(k2, n2)) { set_error("octave out of range"); return ORBX_ERR_BAD_ARG; }
+    std::vector<int32_t> b1(n1), dd1(n1), b2(n2), dd2(n2);
+    int rc = project_best1(m, u1in2, v1in2, radius1, level1, mpdesc1, valid1, n1, k2, d2, n2, minX, maxX, minY, maxY, nullptr, nullptr, nullptr,
+                           b1.data(), dd1.data());
+    if (rc) return rc;
+    rc = project_best1(m, u2in1, v2in1, radius2, level2, mpdesc2, valid2, n2, k1, d1, n1, minX, maxX, minY, maxY, nullptr, nullptr, nullptr,
+                       b2.data(), dd2.data());
+    if (rc) return rc;
+    int found = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {                            // :1224-1227, :1304-1307, agreement :1313-1326
+        const int idx2 = dd1[i1] <= TH_HIGH ? b1[i1] : -1;
+        if (idx2 < 0) continue;
+        const int idx1 = dd2[idx2] <= TH_HIGH ? b2[idx2] : -1;
+        if (idx1 == i1) { match12[i1] = idx2; ++found; }
+    }
+    *nfound = found;
+    return ORBX_OK;
+}
+
+} // extern "C"
+
 extern "C" {
 
 // ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:362-401
