@@ -61,6 +61,43 @@ def main():
                         last_claimed=cl_last, last_n=np.int32(n_last), mp_claimed=cl_mp, mp_n=np.int32(n_mp),
                         stereo_dist=sd, stereo_idx=si, table=table, queries=q, best2=best2)
     print("init", n, "lastframe", n_last, "mappoints", n_mp, "stereo<75", int(((sd >= 0) & (sd < 75)).sum()))
+    around_fixture(k1, d1, k2, d2, scale)
+
+
+def around_fixture(k1, d1, k2, d2, scale):
+    """The steps either side of extraction and the remaining matchers, on small inputs."""
+    rng = np.random.default_rng(7)
+    w, h = 96, 64
+    bgr = np.stack([vsa.synth_frame(50 + c, w, h) for c in range(3)], axis=2)
+    grey = orc.cvt_color_to_gray(bgr, blue_first=True)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    map_x = (xx * np.float32(0.97) + yy * np.float32(0.02) + np.float32(1.3)).astype(np.float32)
+    map_y = (yy * np.float32(1.02) - xx * np.float32(0.015) - np.float32(0.8)).astype(np.float32)
+    rect = orc.remap_linear_u8(grey, map_x, map_y)
+    cam = np.array([517.306408, 516.469215, 318.643040, 255.313989, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+    pts = np.stack([rng.uniform(0, 640, 200), rng.uniform(0, 480, 200)], 1).astype(np.float32)
+    undist = orc.undistort_points(pts, *[float(c) for c in cam])
+    voc = vsa.synth_vocabulary(11, 4, 3)
+    word, node, bow_ids, bow_vals, fv_nodes, fv_ptr, fv_feats = orc.vocabulary_transform(4, 3, *voc, d1[:300], 2)
+    sizes = rng.integers(1, 9, 40)
+    gptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    gdesc = d1[rng.integers(0, len(d1), int(gptr[-1]))] ^ np.packbits(rng.random((int(gptr[-1]), 256)) < 0.1, axis=1)
+    distinct = np.array([orc.distinctive_descriptor(gdesc[gptr[g]:gptr[g + 1]]) for g in range(40)], np.int32)
+    bounds = (0.0, 320.0, 0.0, 240.0)
+    lvl = k1["octave"].astype(np.int32)
+    qu, qv = (k1["x"] + 4).astype(np.float32), (k1["y"] + 2).astype(np.float32)
+    fuse_idx, fuse_dist = orc.fuse_candidates(qu, qv, (3.0 * scale[lvl]).astype(np.float32), lvl, d1, k2, d2, bounds)
+    lvl2 = k2["octave"].astype(np.int32)
+    s1 = (np.ones(len(k1), np.uint8), qu, qv, (7.5 * scale[lvl]).astype(np.float32), lvl, d1)
+    s2 = (np.ones(len(k2), np.uint8), (k2["x"] - 4).astype(np.float32), (k2["y"] - 2).astype(np.float32), (7.5 * scale[lvl2]).astype(np.float32), lvl2, d2)
+    sim3, nsim3 = orc.search_by_sim3(s1, k1, d1, s2, k2, d2, bounds)
+    nodes1, nodes2 = (d1[:, 0] >> 4).astype(np.int64), (d2[:, 0] >> 4).astype(np.int64)
+    b12, b21, nb = orc.search_by_bow(d1, k1["angle"], np.ones(len(k1), np.uint8), nodes1, d2, k2["angle"], None, nodes2, 0.7, True, 0)
+    np.savez_compressed(os.path.join(HERE, "around_96x64.npz"), bgr=bgr, grey=grey, map_x=map_x, map_y=map_y, rect=rect, cam=cam, pts=pts,
+                        undist=undist, voc_parent=voc[0], voc_leaf=voc[1], voc_desc=voc[2], voc_weight=voc[3], word=word, node=node,
+                        bow_ids=bow_ids, bow_vals=bow_vals, fv_nodes=fv_nodes, fv_ptr=fv_ptr, fv_feats=fv_feats, gptr=gptr, gdesc=gdesc,
+                        distinct=distinct, fuse_idx=fuse_idx, fuse_dist=fuse_dist, sim3=sim3, nsim3=np.int32(nsim3), bow21=b21, nbow=np.int32(nb))
+    print("around: words", len(bow_ids), "fused<=50", int((fuse_dist <= 50).sum()), "sim3", nsim3, "bow", nb)
 
 
 if __name__ == "__main__":

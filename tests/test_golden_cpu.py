@@ -28,3 +28,16 @@ def test_oracle_reproduces_match_fixture(oracle):
     m12, n, prev_out = oracle.search_for_initialization(k1, d1, k2, d2, bounds, prev, 30, 0.9, True)
     assert n == int(g["init_n"]) and np.array_equal(m12, g["init_matches12"]) and np.array_equal(prev_out, g["init_prev"])
     assert np.array_equal(oracle.hamming_best2(g["queries"], g["table"]), g["best2"])
+
+
+def test_oracle_reproduces_around_fixture(oracle):
+    g = np.load(os.path.join(GOLD, "around_96x64.npz"))
+    assert np.array_equal(oracle.cvt_color_to_gray(g["bgr"], blue_first=True), g["grey"])
+    assert np.array_equal(oracle.remap_linear_u8(g["grey"], g["map_x"], g["map_y"]), g["rect"])
+    assert np.array_equal(oracle.undistort_points(g["pts"], *[float(c) for c in g["cam"]]), g["undist"])
+    m = np.load(os.path.join(GOLD, "match_320x240.npz"))
+    r = oracle.vocabulary_transform(4, 3, g["voc_parent"], g["voc_leaf"], g["voc_desc"], g["voc_weight"], m["d1"][:300], 2)
+    for got, name in zip(r, ("word", "node", "bow_ids", "bow_vals", "fv_nodes", "fv_ptr", "fv_feats")):
+        assert np.array_equal(got, g[name]), name
+    gp = g["gptr"]
+    assert [oracle.distinctive_descriptor(g["gdesc"][gp[i]:gp[i + 1]]) for i in range(len(gp) - 1)] == g["distinct"].tolist()

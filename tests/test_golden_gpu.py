@@ -54,3 +54,43 @@ def test_match_fixture(vsa):
     got = m.hamming_best2(g["queries"], g["table"])
     assert all(np.array_equal(got[f], g["best2"][f]) for f in ("best", "best_idx", "second"))
     m.close()
+
+
+def test_around_fixture(vsa):
+    """Colour input, rectification, undistortion, vocabulary transform, distinctive descriptors and the remaining matchers
+    against the committed fixture."""
+    g = np.load(os.path.join(GOLD, "around_96x64.npz"))
+    mt = np.load(os.path.join(GOLD, "match_320x240.npz"))
+    k1, d1, k2, d2 = mt["k1"], mt["d1"], mt["k2"], mt["d2"]
+    h, w = g["grey"].shape
+    ex = vsa.Extractor(vsa.make_params(100, 1.2, 1), w, h, device=0)
+    ex.set_input_format("bgr")
+    ex.extract(g["bgr"])
+    assert np.array_equal(ex.pyramid_level(0, 0)[19:-19, 19:-19], g["grey"])
+    cam = vsa.Camera(*[float(c) for c in g["cam"]])
+    assert np.array_equal(ex.undistort_points(cam, g["pts"]), g["undist"])
+    ex.close()
+    rm = vsa.Remapper(g["map_x"], g["map_y"], w, h, device=0)
+    assert np.array_equal(rm.remap(g["grey"]), g["rect"])
+    rm.close()
+    voc = vsa.Vocabulary(4, 3, g["voc_parent"], g["voc_leaf"], g["voc_desc"], g["voc_weight"], device=0)
+    ids, vals, fn, fp, ff = voc.transform(d1[:300], 2)
+    assert np.array_equal(ids, g["bow_ids"]) and np.array_equal(vals, g["bow_vals"])
+    assert np.array_equal(fn, g["fv_nodes"]) and np.array_equal(fp, g["fv_ptr"]) and np.array_equal(ff, g["fv_feats"])
+    voc.close()
+    m = vsa.Matcher(device=0)
+    assert np.array_equal(m.distinctive_descriptors(g["gdesc"], g["gptr"]), g["distinct"])
+    scale = vsa.scale_tables(vsa.make_params(500, 1.2, 4))["scale"]
+    bounds = (0.0, 320.0, 0.0, 240.0)
+    lvl = k1["octave"].astype(np.int32); lvl2 = k2["octave"].astype(np.int32)
+    qu, qv = (k1["x"] + 4).astype(np.float32), (k1["y"] + 2).astype(np.float32)
+    bi, bd = m.project_best1(qu, qv, (3.0 * scale[lvl]).astype(np.float32), lvl, d1, k2, d2, bounds)
+    assert np.array_equal(bi, g["fuse_idx"]) and np.array_equal(bd, g["fuse_dist"])
+    s1 = (np.ones(len(k1), np.uint8), qu, qv, (7.5 * scale[lvl]).astype(np.float32), lvl, d1)
+    s2 = (np.ones(len(k2), np.uint8), (k2["x"] - 4).astype(np.float32), (k2["y"] - 2).astype(np.float32), (7.5 * scale[lvl2]).astype(np.float32), lvl2, d2)
+    m12, n = m.search_by_sim3(s1, k1, d1, s2, k2, d2, bounds)
+    assert n == int(g["nsim3"]) and np.array_equal(m12, g["sim3"])
+    nodes1, nodes2 = (d1[:, 0] >> 4).astype(np.int64), (d2[:, 0] >> 4).astype(np.int64)
+    r = m.search_by_bow(d1, k1["angle"], np.ones(len(k1), np.uint8), nodes1, d2, k2["angle"], None, nodes2, 0.7, True, 0)
+    assert r[2] == int(g["nbow"]) and np.array_equal(r[1], g["bow21"])
+    m.close()
