@@ -67,70 +67,100 @@ __device__ __forceinline__ uint32_t remap_pixel(const uint8_t* __restrict__ src,
         v11 = x1 && y1 ? src[(long long)(sy + 1) * stride + sx + 1] : 0;
     }
     const int sum = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
-    return (uint32_t)min((sum + (1 << 14)) >> 15, 255);
+    return (uint32_t)min((sum + (1 << 14)) >> 15, 255);          // the table form, kept literal on this (rare) path
 }
 
 struct __attribute__((packed, aligned(1))) u64_unaligned { uint32_t x, y; };
 struct __attribute__((packed, aligned(4))) u128_aligned4 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(2))) u64_aligned2 { uint32_t x, y; };
 
-__device__ __forceinline__ uint32_t blend(int v00, int v01, int v10, int v11, uint32_t f)
+// The Q15 table entry for fraction (a, b) / 32 is 32 * (32-b or b) * (32-a or a) (exact), so the blend equals
+// ((32-b) * ((32-a) v00 + a v01) + b * ((32-a) v10 + a v11) + 512) >> 10; the zero-fraction entry (32767, 0, 0, 1) gives
+// v00 + ((v11 - v00 + 16384) >> 15) = v00, which the same expression yields.  wx = (32-a) | a << 8 and sel picks the two
+// adjacent source bytes of a row out of an 8-byte window.
+__device__ __forceinline__ uint32_t blend_rows(uint32_t a_lo, uint32_t a_hi, uint32_t b_lo, uint32_t b_hi, uint32_t sel, uint32_t wx, uint32_t ib, uint32_t b)
 {
-    const int a = (int)(f & 31), b = (int)(f >> 5);
-    int w00 = (32 - b) * (32 - a) * 32, w01 = (32 - b) * a * 32, w10 = b * (32 - a) * 32, w11 = b * a * 32;
-    if (f == 0) { w00 = 32767; w11 = 1; }
-    return (uint32_t)min((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15, 255);
+    const uint32_t top = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(a_hi, a_lo, sel), wx, 0u, false);
+    const uint32_t bot = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(b_hi, b_lo, sel), wx, 0u, false);
+    return (ib * top + b * bot + 512u) >> 10;
 }
+
+constexpr int kRemapFrames = 4;      // frames per thread: the map entries and weights of a quad are set up once for all of them
 
 __global__ __launch_bounds__(256) void k_remap(const uint8_t* __restrict__ src, long long src_stride, long long src_frame, int sw, int sh,
                                                const uint32_t* __restrict__ xy, const uint16_t* __restrict__ frac, int dw, int dh, int qpr,
-                                               uint8_t* __restrict__ dst, long long dst_stride, long long dst_frame)
+                                               uint8_t* __restrict__ dst, long long dst_stride, long long dst_frame, int n_frames)
 {
     const int q = blockIdx.x * 256 + threadIdx.x;          // quad index inside the frame
     if (q >= qpr * dh) return;
     const int y = q / qpr, x = (q - y * qpr) * 4;
-    const uint8_t* s = src + (long long)blockIdx.y * src_frame;
-    uint8_t* d = dst + (long long)blockIdx.y * dst_frame + (long long)y * dst_stride + x;
+    const int f0 = blockIdx.y * kRemapFrames, nf = min(kRemapFrames, n_frames - f0);
+    const uint8_t* s = src + (long long)f0 * src_frame;
+    uint8_t* d = dst + (long long)f0 * dst_frame + (long long)y * dst_stride + x;
     const size_t m = (size_t)y * dw + x;
-    uint32_t out = 0;
-    bool done = false;
     if (x + 4 <= dw) {
-        // smooth maps: the four pixels read one source row pair and at most eight adjacent columns, so two 8-byte loads
-        // serve all sixteen taps
         const u128_aligned4 p = *reinterpret_cast<const u128_aligned4*>(xy + m);
         const u64_aligned2 fr = *reinterpret_cast<const u64_aligned2*>(frac + m);
         const uint32_t pk[4] = {p.x, p.y, p.z, p.w};
         const uint32_t fk[4] = {fr.x & 0xFFFFu, fr.x >> 16, fr.y & 0xFFFFu, fr.y >> 16};
-        const int sy = (int)(short)(p.x >> 16), sx0 = (int)(short)(p.x & 0xFFFF);
-        bool fast = (unsigned)sy < (unsigned)max(sh - 1, 0) && sx0 >= 0 && sx0 + 8 <= sw;
-        int off[4];
+        // smooth maps: the four pixels read at most three adjacent source rows and eight adjacent columns, so three 8-byte
+        // loads serve all sixteen taps (a pixel whose row is one below the quad's first takes rows 1 and 2)
+        int sxk[4], syk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sxk[k] = (int)(short)(pk[k] & 0xFFFF); syk[k] = (int)(short)(pk[k] >> 16); }
+        const int sxb = min(min(sxk[0], sxk[1]), min(sxk[2], sxk[3])), syb = min(min(syk[0], syk[1]), min(syk[2], syk[3]));
+        bool fast = syb >= 0 && sxb >= 0 && sxb + 8 <= sw;
+        uint32_t sel[4], wx[4], wb[4], wib[4];
+        bool down[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            off[k] = (int)(short)(pk[k] & 0xFFFF) - sx0;
-            fast = fast && (int)(short)(pk[k] >> 16) == sy && (unsigned)off[k] <= 6u;
+            const int off = sxk[k] - sxb, dy = syk[k] - syb;
+            fast = fast && (unsigned)off <= 6u && (unsigned)dy <= 1u && syk[k] < sh - 1;
+            down[k] = dy != 0;
+            const uint32_t a = fk[k] & 31u;
+            sel[k] = 0x0c0c0000u | (uint32_t)off | ((uint32_t)(off + 1) << 8);
+            wx[k] = (32u - a) | (a << 8);
+            wb[k] = fk[k] >> 5; wib[k] = 32u - wb[k];
         }
+        const bool aligned = (((uintptr_t)d) & 3) == 0 && (dst_frame & 3) == 0;
         if (fast) {
-            const uint8_t* r0 = s + (long long)sy * src_stride + sx0;
-            const u64_unaligned a = *reinterpret_cast<const u64_unaligned*>(r0), b = *reinterpret_cast<const u64_unaligned*>(r0 + src_stride);
-            const unsigned long long ra = ((unsigned long long)a.y << 32) | a.x, rb = ((unsigned long long)b.y << 32) | b.x;
+            const uint8_t* r0 = s + (long long)syb * src_stride + sxb;
+            const long long third = (long long)(min(syb + 2, sh - 1) - syb) * src_stride;     // row syb+2 exists whenever a pixel needs it
+            u64_unaligned ra[kRemapFrames], rb[kRemapFrames], rc[kRemapFrames];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int sh8 = 8 * off[k];
-                out |= blend((int)((ra >> sh8) & 255), (int)((ra >> (sh8 + 8)) & 255), (int)((rb >> sh8) & 255), (int)((rb >> (sh8 + 8)) & 255), fk[k]) << (8 * k);
-            }
-            done = true;
+            for (int f = 0; f < kRemapFrames; ++f)
+                if (f < nf) {
+                    ra[f] = *reinterpret_cast<const u64_unaligned*>(r0 + f * src_frame);
+                    rb[f] = *reinterpret_cast<const u64_unaligned*>(r0 + f * src_frame + src_stride);
+                    rc[f] = *reinterpret_cast<const u64_unaligned*>(r0 + f * src_frame + third);
+                }
+#pragma unroll
+            for (int f = 0; f < kRemapFrames; ++f)
+                if (f < nf) {
+                    uint32_t out = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        out |= blend_rows(down[k] ? rb[f].x : ra[f].x, down[k] ? rb[f].y : ra[f].y, down[k] ? rc[f].x : rb[f].x,
+                                          down[k] ? rc[f].y : rb[f].y, sel[k], wx[k], wib[k], wb[k]) << (8 * k);
+                    uint8_t* o = d + f * dst_frame;
+                    if (aligned) *reinterpret_cast<uint32_t*>(o) = out;
+                    else for (int k = 0; k < 4; ++k) o[k] = (uint8_t)(out >> (8 * k));
+                }
         } else {
+            for (int f = 0; f < nf; ++f) {
+                uint32_t out = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) out |= remap_pixel(s, src_stride, sw, sh, pk[k], fk[k]) << (8 * k);
-            done = true;
+                for (int k = 0; k < 4; ++k) out |= remap_pixel(s + f * src_frame, src_stride, sw, sh, pk[k], fk[k]) << (8 * k);
+                uint8_t* o = d + f * dst_frame;
+                if (aligned) *reinterpret_cast<uint32_t*>(o) = out;
+                else for (int k = 0; k < 4; ++k) o[k] = (uint8_t)(out >> (8 * k));
+            }
         }
+    } else {
+        for (int f = 0; f < nf; ++f)
+            for (int k = 0; k < 4 && x + k < dw; ++k)
+                d[f * dst_frame + k] = (uint8_t)remap_pixel(s + f * src_frame, src_stride, sw, sh, xy[m + k], frac[m + k]);
     }
-    if (!done) {
-        for (int k = 0; k < 4; ++k)
-            if (x + k < dw) out |= remap_pixel(s, src_stride, sw, sh, xy[m + k], frac[m + k]) << (8 * k);
-    }
-    if (x + 4 <= dw && (((uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t*>(d) = out;
-    else for (int k = 0; k < 4 && x + k < dw; ++k) d[k] = (uint8_t)(out >> (8 * k));
 }
 
 } // namespace
@@ -194,9 +224,9 @@ int orbx_remap_batch_device(orbx_remapper* r, const uint8_t* d_src, ptrdiff_t sr
     if (n_frames == 0) return ORBX_OK;
     HIP_CHECK(hipSetDevice(r->device));
     const int qpr = (r->dw + 3) / 4;
-    hipLaunchKernelGGL(k_remap, dim3((unsigned)(((long long)qpr * r->dh + 255) / 256), n_frames), dim3(256), 0, (hipStream_t)stream, d_src,
-                       (long long)src_row_stride, (long long)src_frame_stride, r->sw, r->sh, r->d_xy, r->d_frac, r->dw, r->dh, qpr, d_dst,
-                       (long long)dst_row_stride, (long long)dst_frame_stride);
+    hipLaunchKernelGGL(k_remap, dim3((unsigned)(((long long)qpr * r->dh + 255) / 256), (n_frames + kRemapFrames - 1) / kRemapFrames), dim3(256), 0,
+                       (hipStream_t)stream, d_src, (long long)src_row_stride, (long long)src_frame_stride, r->sw, r->sh, r->d_xy, r->d_frac,
+                       r->dw, r->dh, qpr, d_dst, (long long)dst_row_stride, (long long)dst_frame_stride, n_frames);
     HIP_CHECK(hipGetLastError());
     return ORBX_OK;
 }
