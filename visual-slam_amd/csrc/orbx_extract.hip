@@ -1142,40 +1142,35 @@ __global__ __launch_bounds__(256) void k_stereo_refine(const uint8_t* __restrict
     if (lane == 0) { uright[row] = out_u; depth[row] = out_d; sad[row] = out_s; }
 }
 
-// Median filter of the accepted SAD distances (src/Frame.cc:626-639): one workgroup per pair.  The reference sorts
-// (distance, left index) pairs and takes element size/2; the rank of a pair is the number of smaller packed keys.
+// Median filter of the accepted SAD distances (src/Frame.cc:626-639).  The reference sorts (distance, left index) pairs
+// and uses the distance of element size/2.
 __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict__ nl_arr, int cap, const int32_t* __restrict__ sad,
-                                                       float* __restrict__ uright, float* __restrict__ depth)
+                                                       float* __restrict__ uright, float* __restrict__ depth, int n_pairs)
 {
-    extern __shared__ uint32_t s_key[];
-    __shared__ int s_nv, s_median;
-    const int pair = blockIdx.x;
+    // one wavefront per pair; the median (element size/2 of the sorted distances, src/Frame.cc:626-629) is a value, so it
+    // is found by bisection on the value with a count per step: no sort, no workgroup barrier
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= n_pairs) return;
     const int nl = min(nl_arr[pair], cap);
     const size_t base = (size_t)pair * cap;
-    if (threadIdx.x == 0) { s_nv = 0; s_median = -1; }
-    __syncthreads();
-    int mine = 0;
-    for (int i = threadIdx.x; i < nl; i += 256) {
-        const int s = sad[base + i];
-        s_key[i] = s >= 0 ? ((uint32_t)s << 16) | (uint32_t)i : 0xFFFFFFFFu;
-        mine += s >= 0;
-    }
-    if (mine) atomicAdd(&s_nv, mine);
-    __syncthreads();
-    const int nv = s_nv;
+    int nv = 0;
+    for (int i = lane; i < nl; i += 64) nv += sad[base + i] >= 0;
+    for (int d = 32; d >= 1; d >>= 1) nv += __shfl_xor(nv, d, 64);
     if (nv == 0) return;
-    for (int i = threadIdx.x; i < nl; i += 256) {
-        const uint32_t key = s_key[i];
-        if (key == 0xFFFFFFFFu) continue;
-        int rank = 0;
-        for (int j = 0; j < nl; ++j) rank += s_key[j] < key;
-        if (rank == nv / 2) s_median = (int)(key >> 16);
+    const int kth = nv / 2;
+    int lo = 0, hi = 1 << 16;                               // least v with #{s : 0 <= s <= v} > kth; an 11x11 SAD is at most 30 855
+    while (lo < hi) {
+        const int v = lo + ((hi - lo) >> 1);
+        int cnt = 0;
+        for (int i = lane; i < nl; i += 64) { const int sv = sad[base + i]; cnt += sv >= 0 && sv <= v; }
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if (cnt > kth) hi = v; else lo = v + 1;
     }
-    __syncthreads();
-    const float thDist = 1.5f * 1.4f * (float)s_median;
-    for (int i = threadIdx.x; i < nl; i += 256) {
-        const uint32_t key = s_key[i];
-        if (key != 0xFFFFFFFFu && !((float)(key >> 16) < thDist)) { uright[base + i] = -1.0f; depth[base + i] = -1.0f; }
+    const float thDist = 1.5f * 1.4f * (float)lo;
+    for (int i = lane; i < nl; i += 64) {
+        const int sv = sad[base + i];
+        if (sv >= 0 && !((float)sv < thDist)) { uright[base + i] = -1.0f; depth[base + i] = -1.0f; }
     }
 }
 
@@ -1739,8 +1734,7 @@ int orbx_stereo_refine_batch_device(orbx_extractor* left, orbx_extractor* right,
     hipLaunchKernelGGL(k_stereo_refine, dim3((cap_per_frame + 3) / 4, n_pairs), dim3(256), 0, st, left->d_pyr, right->d_pyr,
                        (unsigned long long)left->geo.pyr_bytes, left->d_lv, left->geo.nlevels, d_kl, d_nl, d_kr, cap_per_frame,
                        d_best_dist, d_best_idx, bf, min_d, max_d, d_uright, d_depth, d_sad);
-    hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(256), sizeof(uint32_t) * (size_t)cap_per_frame, st, d_nl, cap_per_frame,
-                       d_sad, d_uright, d_depth);
+    hipLaunchKernelGGL(k_stereo_median, dim3((n_pairs + 3) / 4), dim3(256), 0, st, d_nl, cap_per_frame, d_sad, d_uright, d_depth, n_pairs);
     HIP_CHECK(hipGetLastError());
     return ORBX_OK;
 }

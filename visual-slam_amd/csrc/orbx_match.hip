@@ -149,74 +149,106 @@ __global__ __launch_bounds__(256) void k_csr_dist(const uint32_t* __restrict__ q
     }
 }
 
-// Stereo row-band search (src/Frame.cc:476-549): one thread per left keypoint, right keypoints of
-// the pair staged in LDS and walked in index order (the order of vRowIndices[row]).
-constexpr int kStereoChunk = 512;
+// Stereo row-band search (src/Frame.cc:476-549).  One workgroup per pair builds the reference's vRowIndices table
+// (for every image row the right keypoints whose band of +-2*scale rows covers it; counts and offsets in LDS, the index
+// lists in a device-memory slice of the workgroup), then one thread per left keypoint walks the list of its row only.
+// The best candidate is the minimum of distance << 16 | index, which is what the reference's strict '<' over lists in
+// ascending index order keeps, so the order in which the lists are filled does not matter.
 __global__ __launch_bounds__(256) void k_stereo(const orbx_keypoint* __restrict__ kl, const uint32_t* __restrict__ dl, const int32_t* __restrict__ nl_arr,
                                                 const orbx_keypoint* __restrict__ kr, const uint32_t* __restrict__ dr, const int32_t* __restrict__ nr_arr,
                                                 int cap, int nl_fixed, int nr_fixed,
                                                 const float* __restrict__ scale, int n_rows, float min_d, float max_d,
+                                                uint16_t* __restrict__ lists, unsigned long long list_stride,
                                                 int32_t* __restrict__ best_dist, int32_t* __restrict__ best_idx)
 {
-    __shared__ float s_x[kStereoChunk];
-    __shared__ int s_minr[kStereoChunk], s_maxr[kStereoChunk], s_oct[kStereoChunk];
-    __shared__ uint32_t s_d[kStereoChunk * 8];
-    const int pair = blockIdx.y;
+    extern __shared__ int32_t s_mem[];
+    int32_t* s_start = s_mem;                      // n_rows + 1: first list entry of a row
+    int32_t* s_fill = s_mem + (n_rows + 1);        // n_rows + 1: counts, then fill positions
+    float* s_x = reinterpret_cast<float*>(s_mem + 2 * (n_rows + 1));      // right keypoint columns
+    uint8_t* s_oct = reinterpret_cast<uint8_t*>(s_x + cap);               // right keypoint octaves
+    __shared__ int32_t s_part[256];
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.x;
     const int nl = nl_arr ? min(nl_arr[pair], cap) : nl_fixed;
     const int nr = nr_arr ? min(nr_arr[pair], cap) : nr_fixed;
     const size_t base = (size_t)pair * cap;
-    const int iL = blockIdx.x * 256 + threadIdx.x;
-    const bool active = iL < nl;
-    uint32_t qv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int row = -1, levelL = 0;
-    float minU = 0.f, maxU = -1.f;
-    if (active) {
-        const orbx_keypoint k = kl[base + iL];
-        levelL = k.octave;
-        row = (int)k.y;
-        minU = __fsub_rn(k.x, max_d);
-        maxU = __fsub_rn(k.x, min_d);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qv[i] = dl[(base + iL) * 8 + i];
+    uint16_t* list = lists + (unsigned long long)pair * list_stride;
+    for (int i = tid; i <= n_rows; i += 256) s_fill[i] = 0;
+    __syncthreads();
+    // bands of the right keypoints (:483-493), clipped to the image rows
+    for (int i = tid; i < nr; i += 256) {
+        const orbx_keypoint k = kr[base + i];
+        const float r = __fmul_rn(2.0f, scale[k.octave]);
+        const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), n_rows - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
+        s_x[i] = k.x; s_oct[i] = (uint8_t)k.octave;
+        for (int yi = minr; yi <= maxr; ++yi) atomicAdd(&s_fill[yi], 1);
     }
-    const bool rowok = active && row >= 0 && row < n_rows;
-    uint32_t best = (100u << 16);
-    bool anyRow = false;
-    for (int c0 = 0; c0 < nr; c0 += kStereoChunk) {
-        const int m = min(kStereoChunk, nr - c0);
+    __syncthreads();
+    // exclusive prefix sum of the row counts: a contiguous chunk per thread, then a scan of the chunk totals
+    const int chunk = (n_rows + 256) / 256;
+    const int c0 = tid * chunk, c1 = min(c0 + chunk, n_rows + 1);
+    int sum = 0;
+    for (int i = c0; i < c1; ++i) sum += s_fill[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = tid >= d ? s_part[tid - d] : 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < m; i += 256) {
-            const orbx_keypoint k = kr[base + c0 + i];
-            const float r = __fmul_rn(2.0f, scale[k.octave]);
-            s_x[i] = k.x;
-            s_maxr[i] = (int)ceilf(__fadd_rn(k.y, r));
-            s_minr[i] = (int)floorf(__fsub_rn(k.y, r));
-            s_oct[i] = k.octave;
-        }
-        for (int i = threadIdx.x; i < m * 8; i += 256) s_d[i] = dr[(base + c0) * 8 + i];
+        s_part[tid] += v;
         __syncthreads();
-        if (rowok) {
-            for (int i = 0; i < m; ++i) {
-                if (row < s_minr[i] || row > s_maxr[i]) continue;
-                anyRow = true;
+    }
+    int run = s_part[tid] - sum;
+    for (int i = c0; i < c1; ++i) { const int c = s_fill[i]; s_start[i] = run; s_fill[i] = run; run += c; }
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) {
+        const orbx_keypoint k = kr[base + i];
+        const float r = __fmul_rn(2.0f, scale[k.octave]);
+        const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), n_rows - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
+        for (int yi = minr; yi <= maxr; ++yi) list[atomicAdd(&s_fill[yi], 1)] = (uint16_t)i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int iL = tid; iL < nl; iL += 256) {
+        const orbx_keypoint k = kl[base + iL];
+        const int levelL = k.octave;
+        const int row = (int)k.y;                                   // vRowIndices[vL], :509-511
+        const float minU = __fsub_rn(k.x, max_d), maxU = __fsub_rn(k.x, min_d);
+        const bool rowok = row >= 0 && row < n_rows;
+        const int b = rowok ? s_start[row] : 0, e = rowok ? s_start[row + 1] : 0;
+        const bool skipped = e == b || (maxU < 0);                  // :513-520
+        uint32_t best = (100u << 16);                               // bestDist = TH_HIGH, bestIdxR = 0 (:522-523)
+        if (!skipped) {
+            uint32_t qv[8];
+            { const uint4* qp = reinterpret_cast<const uint4*>(dl + (base + iL) * 8);
+              const uint4 a = qp[0], c = qp[1];
+              qv[0] = a.x; qv[1] = a.y; qv[2] = a.z; qv[3] = a.w; qv[4] = c.x; qv[5] = c.y; qv[6] = c.z; qv[7] = c.w; }
+            for (int c = b; c < e; ++c) {
+                const int i = list[c];
                 const int o = s_oct[i];
                 if (o < levelL - 1 || o > levelL + 1) continue;
                 const float uR = s_x[i];
                 if (uR >= minU && uR <= maxU) {
-                    uint32_t d = 0;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) d += __popc(qv[w] ^ s_d[i * 8 + w]);
-                    best = min(best, (d << 16) | (uint32_t)(c0 + i));
+                    const uint4* tp = reinterpret_cast<const uint4*>(dr + (base + i) * 8);
+                    const uint4 lo = tp[0], hi = tp[1];
+                    const uint32_t d = __popc(qv[0] ^ lo.x) + __popc(qv[1] ^ lo.y) + __popc(qv[2] ^ lo.z) + __popc(qv[3] ^ lo.w) +
+                                       __popc(qv[4] ^ hi.x) + __popc(qv[5] ^ hi.y) + __popc(qv[6] ^ hi.z) + __popc(qv[7] ^ hi.w);
+                    best = min(best, (d << 16) | (uint32_t)i);
                 }
             }
         }
-    }
-    if (active) {
-        const bool skipped = !rowok || !anyRow || (maxU < 0);
         best_dist[base + iL] = skipped ? -1 : (int)(best >> 16);
         best_idx[base + iL] = skipped ? -1 : (int)(best & 0xFFFF);
     }
 }
+
+// rows a right keypoint's band can span: ceil(y + r) - floor(y - r) + 1 <= 2r + 3 with r = 2 * scale
+static int stereo_band_rows(const float* scale_factors, int nlevels)
+{
+    float smax = 0.f;
+    for (int i = 0; i < nlevels; ++i) smax = std::max(smax, scale_factors[i]);
+    return (int)(4.0f * smax) + 3;
+}
+static size_t stereo_lds_bytes(int n_rows, int cap) { return sizeof(int32_t) * 2 * ((size_t)n_rows + 1) + sizeof(float) * (size_t)cap + (size_t)cap + 16; }
 
 } // namespace
 
@@ -375,10 +407,15 @@ int orbx_stereo_match_batch_device(orbx_matcher* m, const orbx_keypoint* d_kl, c
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = reserve(&m->stage[6], &m->stage_bytes[6], sizeof(float) * kMaxLevels))) return rc;
+    const size_t list_stride = (size_t)cap_per_frame * stereo_band_rows(scale_factors, nlevels);
+    if ((rc = reserve(&m->stage[7], &m->stage_bytes[7], sizeof(uint16_t) * list_stride * (size_t)n_pairs))) return rc;
+    const size_t lds = stereo_lds_bytes(n_rows, cap_per_frame);
+    if (n_rows < 1 || lds > 150 * 1024) { set_error("image rows / keypoint capacity too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_CHECK(hipMemcpyAsync(m->stage[6], scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_stereo, dim3((cap_per_frame + 255) / 256, n_pairs), dim3(256), 0, st, d_kl, (const uint32_t*)d_dl, d_nl,
+    hipLaunchKernelGGL(k_stereo, dim3(n_pairs), dim3(256), lds, st, d_kl, (const uint32_t*)d_dl, d_nl,
                        d_kr, (const uint32_t*)d_dr, d_nr, cap_per_frame, 0, 0, (const float*)m->stage[6], n_rows, min_d, max_d,
-                       d_best_dist, d_best_idx);
+                       (uint16_t*)m->stage[7], (unsigned long long)list_stride, d_best_dist, d_best_idx);
     HIP_CHECK(hipGetLastError());
     return ORBX_OK;
 }
@@ -408,9 +445,15 @@ int orbx_stereo_match(orbx_matcher* m, const orbx_keypoint* kl, const uint8_t* d
         HIP_CHECK(hipMemcpyAsync(m->stage[3], dr, (size_t)nr * 32, hipMemcpyHostToDevice, m->stream));
     }
     HIP_CHECK(hipMemcpyAsync(m->stage[6], scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(k_stereo, dim3((nl + 255) / 256, 1), dim3(256), 0, m->stream, (const orbx_keypoint*)m->stage[0], (const uint32_t*)m->stage[1],
+    const size_t list_stride = (size_t)cap * stereo_band_rows(scale_factors, nlevels);
+    if ((rc = reserve(&m->stage[7], &m->stage_bytes[7], sizeof(uint16_t) * list_stride))) return rc;
+    const size_t lds = stereo_lds_bytes(n_rows, cap);
+    if (n_rows < 1 || lds > 150 * 1024) { set_error("image rows / keypoint count too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_stereo, dim3(1), dim3(256), lds, m->stream, (const orbx_keypoint*)m->stage[0], (const uint32_t*)m->stage[1],
                        (const int32_t*)nullptr, (const orbx_keypoint*)m->stage[2], (const uint32_t*)m->stage[3], (const int32_t*)nullptr, cap, nl, nr,
-                       (const float*)m->stage[6], n_rows, min_d, max_d, (int32_t*)m->stage[4], (int32_t*)m->stage[5]);
+                       (const float*)m->stage[6], n_rows, min_d, max_d, (uint16_t*)m->stage[7], (unsigned long long)list_stride,
+                       (int32_t*)m->stage[4], (int32_t*)m->stage[5]);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(best_dist, m->stage[4], sizeof(int32_t) * (size_t)nl, hipMemcpyDeviceToHost, m->stream));
     HIP_CHECK(hipMemcpyAsync(best_idx, m->stage[5], sizeof(int32_t) * (size_t)nl, hipMemcpyDeviceToHost, m->stream));
