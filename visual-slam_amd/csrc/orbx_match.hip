@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void k_csr_dist(const uint32_t* __restrict__ q
 // lists in a device-memory slice of the workgroup), then one thread per left keypoint walks the list of its row only.
 // The best candidate is the minimum of distance << 16 | index, which is what the reference's strict '<' over lists in
 // ascending index order keeps, so the order in which the lists are filled does not matter.
-__global__ __launch_bounds__(256) void k_stereo(const orbx_keypoint* __restrict__ kl, const uint32_t* __restrict__ dl, const int32_t* __restrict__ nl_arr,
+constexpr int kStereoThreads = 1024;
+__global__ __launch_bounds__(kStereoThreads) void k_stereo(const orbx_keypoint* __restrict__ kl, const uint32_t* __restrict__ dl, const int32_t* __restrict__ nl_arr,
                                                 const orbx_keypoint* __restrict__ kr, const uint32_t* __restrict__ dr, const int32_t* __restrict__ nr_arr,
                                                 int cap, int nl_fixed, int nr_fixed,
                                                 const float* __restrict__ scale, int n_rows, float min_d, float max_d,
@@ -167,16 +168,16 @@ __global__ __launch_bounds__(256) void k_stereo(const orbx_keypoint* __restrict_
     float* s_x = reinterpret_cast<float*>(s_mem + 2 * (n_rows + 1));      // right keypoint columns
     uint8_t* s_oct = reinterpret_cast<uint8_t*>(s_x + cap);               // right keypoint octaves
     __shared__ int32_t s_part[256];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NT = blockDim.x;
     const int pair = blockIdx.x;
     const int nl = nl_arr ? min(nl_arr[pair], cap) : nl_fixed;
     const int nr = nr_arr ? min(nr_arr[pair], cap) : nr_fixed;
     const size_t base = (size_t)pair * cap;
     uint16_t* list = lists + (unsigned long long)pair * list_stride;
-    for (int i = tid; i <= n_rows; i += 256) s_fill[i] = 0;
+    for (int i = tid; i <= n_rows; i += NT) s_fill[i] = 0;
     __syncthreads();
     // bands of the right keypoints (:483-493), clipped to the image rows
-    for (int i = tid; i < nr; i += 256) {
+    for (int i = tid; i < nr; i += NT) {
         const orbx_keypoint k = kr[base + i];
         const float r = __fmul_rn(2.0f, scale[k.octave]);
         const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), n_rows - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
@@ -185,22 +186,26 @@ __global__ __launch_bounds__(256) void k_stereo(const orbx_keypoint* __restrict_
     }
     __syncthreads();
     // exclusive prefix sum of the row counts: a contiguous chunk per thread, then a scan of the chunk totals
-    const int chunk = (n_rows + 256) / 256;
-    const int c0 = tid * chunk, c1 = min(c0 + chunk, n_rows + 1);
+    const int chunk = (n_rows + 256) / 256;                       // the first 256 threads do the scan
+    const int c0 = min(tid * chunk, n_rows + 1), c1 = min(c0 + chunk, n_rows + 1);
     int sum = 0;
-    for (int i = c0; i < c1; ++i) sum += s_fill[i];
-    s_part[tid] = sum;
+    if (tid < 256) {
+        for (int i = c0; i < c1; ++i) sum += s_fill[i];
+        s_part[tid] = sum;
+    }
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
-        const int v = tid >= d ? s_part[tid - d] : 0;
+        const int v = tid < 256 && tid >= d ? s_part[tid - d] : 0;
         __syncthreads();
-        s_part[tid] += v;
+        if (tid < 256) s_part[tid] += v;
         __syncthreads();
     }
-    int run = s_part[tid] - sum;
-    for (int i = c0; i < c1; ++i) { const int c = s_fill[i]; s_start[i] = run; s_fill[i] = run; run += c; }
+    if (tid < 256) {
+        int run = s_part[tid] - sum;
+        for (int i = c0; i < c1; ++i) { const int c = s_fill[i]; s_start[i] = run; s_fill[i] = run; run += c; }
+    }
     __syncthreads();
-    for (int i = tid; i < nr; i += 256) {
+    for (int i = tid; i < nr; i += NT) {
         const orbx_keypoint k = kr[base + i];
         const float r = __fmul_rn(2.0f, scale[k.octave]);
         const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), n_rows - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void k_stereo(const orbx_keypoint* __restrict_
     }
     __threadfence_block();
     __syncthreads();
-    for (int iL = tid; iL < nl; iL += 256) {
+    for (int iL = tid; iL < nl; iL += NT) {
         const orbx_keypoint k = kl[base + iL];
         const int levelL = k.octave;
         const int row = (int)k.y;                                   // vRowIndices[vL], :509-511
@@ -413,7 +418,7 @@ int orbx_stereo_match_batch_device(orbx_matcher* m, const orbx_keypoint* d_kl, c
     if (n_rows < 1 || lds > 150 * 1024) { set_error("image rows / keypoint capacity too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_CHECK(hipMemcpyAsync(m->stage[6], scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_stereo, dim3(n_pairs), dim3(256), lds, st, d_kl, (const uint32_t*)d_dl, d_nl,
+    hipLaunchKernelGGL(k_stereo, dim3(n_pairs), dim3(kStereoThreads), lds, st, d_kl, (const uint32_t*)d_dl, d_nl,
                        d_kr, (const uint32_t*)d_dr, d_nr, cap_per_frame, 0, 0, (const float*)m->stage[6], n_rows, min_d, max_d,
                        (uint16_t*)m->stage[7], (unsigned long long)list_stride, d_best_dist, d_best_idx);
     HIP_CHECK(hipGetLastError());
@@ -450,7 +455,7 @@ int orbx_stereo_match(orbx_matcher* m, const orbx_keypoint* kl, const uint8_t* d
     const size_t lds = stereo_lds_bytes(n_rows, cap);
     if (n_rows < 1 || lds > 150 * 1024) { set_error("image rows / keypoint count too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_stereo, dim3(1), dim3(256), lds, m->stream, (const orbx_keypoint*)m->stage[0], (const uint32_t*)m->stage[1],
+    hipLaunchKernelGGL(k_stereo, dim3(1), dim3(kStereoThreads), lds, m->stream, (const orbx_keypoint*)m->stage[0], (const uint32_t*)m->stage[1],
                        (const int32_t*)nullptr, (const orbx_keypoint*)m->stage[2], (const uint32_t*)m->stage[3], (const int32_t*)nullptr, cap, nl, nr,
                        (const float*)m->stage[6], n_rows, min_d, max_d, (uint16_t*)m->stage[7], (unsigned long long)list_stride,
                        (int32_t*)m->stage[4], (int32_t*)m->stage[5]);
