@@ -263,3 +263,35 @@ def test_undistort_keypoints(vsa, oracle):
             assert np.array_equal(np.stack([uu["x"], uu["y"]], 1).view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
             assert np.all(u[f, c[f]:]["x"] == -7.0)                                # rows past the count untouched
     ex.close()
+
+
+def test_full_size_batch_kitti_shape(vsa, oracle):
+    """The largest workload of the benchmark plan at full size: 4096 frames of 1241x376 with 2000 features in one call
+    (tens of GB of working set: every per-frame offset must be computed in 64 bits).  Sixteen distinct frames are tiled,
+    so every group of sixteen outputs must repeat the first one exactly, and the first group equals the oracle."""
+    import torch
+    w, h, B, U = 1241, 376, 4096, 16
+    p = vsa.make_params(2000)
+    uniq = np.stack([vsa.synth_frame(300 + i, w, h) for i in range(U)])
+    frames = torch.from_numpy(uniq).cuda().repeat(B // U, 1, 1).contiguous()
+    ex = vsa.Extractor(p, w, h, max_batch=B, device=0)
+    cap = ex.cap
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(frames.data_ptr(), w, w * h, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap,
+                            torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy().reshape(B // U, U)
+    assert np.all(c == c[0]) and c.min() > 1500
+    assert torch.equal(desc.view(B // U, U, cap, 32), desc[:U].unsqueeze(0).expand(B // U, U, cap, 32))
+    kbits = kps.view(torch.int32)                                      # class_id -1 reads as NaN in the float view
+    assert torch.equal(kbits.view(B // U, U, cap, 7), kbits[:U].unsqueeze(0).expand(B // U, U, cap, 7))
+    oex = oracle.Extractor(oracle.make_params(2000))
+    for f in (0, 7, 15):
+        ok, od = oex.extract(uniq[f])
+        n = int(c[0, f])
+        assert n == len(ok)
+        assert np.array_equal(desc[B - U + f, :n].cpu().numpy(), od)
+        assert np.array_equal(kps[B - U + f, :n].cpu().numpy().view(vsa.KEYPOINT_DTYPE).reshape(n), ok.astype(vsa.KEYPOINT_DTYPE))
+    ex.close()
