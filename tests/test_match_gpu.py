@@ -83,6 +83,32 @@ def test_best2_large_property(vsa, oracle, matcher):
     assert eq_best2(got[:8], want)
 
 
+def test_best2_full_size_and_sharded(vsa, oracle, matcher):
+    """The map-matching workload at full size (4096 queries x 2^24 rows, 512 MiB of descriptors) in one pass, and the
+    same map cut into 8 contiguous shards whose results are merged the way the ranks of a multi-GPU run merge theirs:
+    both must agree exactly; planted rows are found; two queries are checked against the oracle."""
+    import torch
+    nt, nq, shards = 1 << 24, 4096, 8
+    table = vsa.synth_descriptors(42, nt)
+    q, src = vsa.synth_queries(43, table, nq)
+    d_t = torch.from_numpy(table).cuda(); d_q = torch.from_numpy(q).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    whole = torch.zeros((nq, 4), dtype=torch.int32, device="cuda")
+    matcher.hamming_best2_device(d_q.data_ptr(), nq, d_t.data_ptr(), nt, 0, whole.data_ptr(), st)
+    parts = torch.zeros((shards, nq, 4), dtype=torch.int32, device="cuda")
+    rows = nt // shards
+    for s in range(shards):
+        matcher.hamming_best2_device(d_q.data_ptr(), nq, d_t[s * rows:].data_ptr(), rows, s * rows, parts[s].data_ptr(), st)
+    merged = torch.zeros((nq, 4), dtype=torch.int32, device="cuda")
+    matcher.best2_merge_device(parts.data_ptr(), shards, nq, merged.data_ptr(), st)
+    torch.cuda.synchronize()
+    w = whole.cpu().numpy(); mg = merged.cpu().numpy()
+    assert np.array_equal(w[:, :3], mg[:, :3])
+    assert (w[:, 1] == src).mean() > 0.99 and (w[:, 2] >= w[:, 0]).all()
+    want = oracle.hamming_best2(q[:2], table)
+    assert np.array_equal(w[:2, 0], want["best"]) and np.array_equal(w[:2, 1], want["best_idx"]) and np.array_equal(w[:2, 2], want["second"])
+
+
 def test_csr_distances(vsa, oracle, matcher):
     rng = np.random.default_rng(3)
     t = vsa.synth_descriptors(5, 900)
