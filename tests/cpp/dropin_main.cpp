@@ -4,9 +4,11 @@
 #include "../../visual-slam_amd/cpp/ORBmatcher.h"
 #include "../../visual-slam_amd/cpp/ORBVocabulary.h"
 #include <string>
+#include <thread>
 #include <cstdio>
 #include <ctime>
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 
 static void dump(FILE* f, const void* p, size_t n) { fwrite(p, 1, n, f); }
@@ -62,6 +64,21 @@ int main(int argc, char** argv)
     cv::Mat dL, dR;
     left(imL, cv::Mat(), kL, dL);
     right(imR, cv::Mat(), kR, dR);
+    // the two extractors of a stereo frame run in two threads (src/Frame.cc:78-81): results must not depend on it
+    for (int rep = 0; rep < 10; ++rep) {
+        std::vector<cv::KeyPoint> kL2, kR2;
+        cv::Mat dL2, dR2;
+        std::thread threadLeft([&]() { left(imL, cv::Mat(), kL2, dL2); });
+        std::thread threadRight([&]() { right(imR, cv::Mat(), kR2, dR2); });
+        threadLeft.join();
+        threadRight.join();
+        if (kL2.size() != kL.size() || kR2.size() != kR.size() || memcmp(kL2.data(), kL.data(), kL.size() * sizeof(cv::KeyPoint)) ||
+            memcmp(kR2.data(), kR.data(), kR.size() * sizeof(cv::KeyPoint)) || memcmp(dL2.ptr(), dL.ptr(), (size_t)dL.rows * 32) ||
+            memcmp(dR2.ptr(), dR.ptr(), (size_t)dR.rows * 32)) {
+            fprintf(stderr, "concurrent extraction differs from sequential extraction\n");
+            return 8;
+        }
+    }
     const float bf = 47.90639384423901f, fx = 435.2046959714599f;
     std::vector<float> uRight, depth;
     matcher.ComputeStereoMatches(left, right, kL, dL, kR, dR, bf, bf / fx, uRight, depth);
