@@ -612,6 +612,7 @@ size_t ot_lds_bytes(int NC, int nthreads, int KL)
     return o + (size_t)KL * 6 + 16;
 }
 
+template <bool kTablesInDeviceMemory>
 __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
                                                         const uint32_t* __restrict__ cand, int cand_total,
                                                         const uint16_t* __restrict__ cellcnt, int ncells,
@@ -628,8 +629,9 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
     OtShared s;
     const int NT = blockDim.x;
     // the node tables live in LDS; a quota too large for it (thousands of keypoints in one level) takes a slice of device
-    // memory instead (gmem != nullptr, KL == 0): the waves of a workgroup share one CU's L1, so barriers order it the same way
-    unsigned char* ot_mem = gmem ? gmem + ((unsigned long long)frame * nlevels + level) * gstride : ot_lds;
+    // memory instead (KL == 0): the waves of a workgroup share one CU's L1, so barriers order it the same way.  A template
+    // parameter rather than a run-time choice, so that the LDS form keeps its DS instructions.
+    unsigned char* ot_mem = kTablesInDeviceMemory ? gmem + ((unsigned long long)frame * nlevels + level) * gstride : ot_lds;
     const size_t keyOff = ot_carve(s, ot_mem, NCmax, kOctThreads);
 
     const uint16_t* cnt = cellcnt + (unsigned long long)frame * ncells + L.cell_first;
@@ -1352,7 +1354,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         ex->oct_lds = 64;
         HIP_CHECK(hipMalloc(&ex->d_octmem, ex->oct_gstride * geo.nlevels * (size_t)max_batch));
     }
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ex->oct_lds));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ex->oct_lds));
     HIP_CHECK(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
     const size_t B = (size_t)max_batch;
     HIP_CHECK(hipMalloc(&ex->d_lv, sizeof(DevLevel) * geo.nlevels));
@@ -1473,11 +1475,14 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
         // frame is the fast grid index: consecutive workgroups go to different XCDs, so every XCD gets an equal
         // share of each level (a level-major order would put all level-0 quadtrees, the largest, on one XCD)
         dim3 grid(B, G.nlevels);
-        hipLaunchKernelGGL(k_octree, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, cand, G.cand_total,
-                           cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp,
-                           G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL,
-                           ex->d_octmem ? ex->d_octmem + (size_t)f0 * G.nlevels * ex->oct_gstride : nullptr,
-                           (unsigned long long)ex->oct_gstride);
+        if (ex->d_octmem)
+            hipLaunchKernelGGL(k_octree<true>, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, cand, G.cand_total,
+                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL,
+                               ex->d_octmem + (size_t)f0 * G.nlevels * ex->oct_gstride, (unsigned long long)ex->oct_gstride);
+        else
+            hipLaunchKernelGGL(k_octree<false>, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, cand, G.cand_total,
+                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL,
+                               (unsigned char*)nullptr, 0ull);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
     {
