@@ -612,6 +612,34 @@ size_t ot_lds_bytes(int NC, int nthreads, int KL)
     return o + (size_t)KL * 6 + 16;
 }
 
+// gathers the per-cell candidate slots of a level into the dense key array K (cell-row-major, raster inside a cell: the
+// reference's vToDistributeKeys order) and runs the quadtree on it
+__device__ __attribute__((always_inline)) int octree_level(OtShared& s, uint32_t* K, uint16_t* NO, int nk, const DevLevel& L,
+                                                            const CellRec* __restrict__ cells, const uint16_t* __restrict__ cnt,
+                                                            const uint32_t* __restrict__ slots, int NCmax, uint32_t* __restrict__ out)
+{
+    const int tid = threadIdx.x, NT = blockDim.x;
+    int base = 0;
+    for (int c0 = 0; c0 < L.cell_count; c0 += NCmax) {
+        const int m = min(NCmax, L.cell_count - c0);
+        for (int i = tid; i < m; i += NT) s.keep[i] = cnt[c0 + i];
+        __syncthreads();
+        const int tot = ot_block_scan(s.keep, m, s.scanTmp);
+        for (int i = tid; i < m; i += NT) {
+            const CellRec& cr = cells[L.cell_first + c0 + i];
+            const int n = cnt[c0 + i];
+            const int o = base + s.keep[i];
+            for (int j = 0; j < n; ++j) K[o + j] = slots[cr.slot + j];
+        }
+        __syncthreads();
+        base += tot;
+    }
+    __threadfence_block();
+    __syncthreads();
+    OtMemKeys ks{K, NO, nk};
+    return ot_distribute(s, ks, K, L.maxBorderY - kMinBorder, L.nIni, L.hX, L.quota, out, L.kp_cap);
+}
+
 template <bool kTablesInDeviceMemory>
 __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
                                                         const uint32_t* __restrict__ cand, int cand_total,
@@ -645,35 +673,16 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
     if ((tid & 63) == 0) atomicAdd(&s_nk, part);
     __syncthreads();
     const int nk = s_nk;
-    uint32_t* K; uint16_t* NO;
-    if (nk <= KL) {
-        K = reinterpret_cast<uint32_t*>(ot_mem + keyOff);
-        NO = reinterpret_cast<uint16_t*>(ot_mem + keyOff + (size_t)KL * 4);
-    } else {
-        K = keys + (unsigned long long)frame * key_total + L.key_offset;
-        NO = nodeOf + (unsigned long long)frame * key_total + L.key_offset;
-    }
-    // gather the per-cell slots into one dense array (cell-row-major, raster inside a cell)
-    int base = 0;
-    for (int c0 = 0; c0 < L.cell_count; c0 += NCmax) {
-        const int m = min(NCmax, L.cell_count - c0);
-        for (int i = tid; i < m; i += NT) s.keep[i] = cnt[c0 + i];
-        __syncthreads();
-        const int tot = ot_block_scan(s.keep, m, s.scanTmp);
-        for (int i = tid; i < m; i += NT) {
-            const CellRec& cr = cells[L.cell_first + c0 + i];
-            const int n = cnt[c0 + i];
-            const int o = base + s.keep[i];
-            for (int j = 0; j < n; ++j) K[o + j] = slots[cr.slot + j];
-        }
-        __syncthreads();
-        base += tot;
-    }
-    __threadfence_block();
-    __syncthreads();
-    uint32_t* out = lvlkp + (unsigned long long)frame * kp_total + L.kp_offset;
-    OtMemKeys ks{K, NO, nk};
-    const int n = ot_distribute(s, ks, K, L.maxBorderY - kMinBorder, L.nIni, L.hX, L.quota, out, L.kp_cap);
+    // two copies of the same code, one per home of the key arrays: with the address space known at compile time the LDS
+    // copy gets DS instructions (a pointer chosen at run time would make every key access a FLAT one)
+    int n;
+    if (nk <= KL)
+        n = octree_level(s, reinterpret_cast<uint32_t*>(ot_mem + keyOff), reinterpret_cast<uint16_t*>(ot_mem + keyOff + (size_t)KL * 4), nk,
+                         L, cells, cnt, slots, NCmax, lvlkp + (unsigned long long)frame * kp_total + L.kp_offset);
+    else
+        n = octree_level(s, keys + (unsigned long long)frame * key_total + L.key_offset,
+                         nodeOf + (unsigned long long)frame * key_total + L.key_offset, nk,
+                         L, cells, cnt, slots, NCmax, lvlkp + (unsigned long long)frame * kp_total + L.kp_offset);
     if (tid == 0) lvlcnt[frame * nlevels + level] = min(n, L.kp_cap);
 }
 
