@@ -194,6 +194,16 @@ int main(int argc, char** argv)
         printf("SearchForInitialization %zu x %zu features, window 100: %.0f us per call\n", k1.size(), k2.size(),
                ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 20e3);
     }
+    {   // SearchByBoW(KeyFrame*, Frame&) as Tracking::TrackReferenceKeyFrame calls it (information only)
+        struct timespec t0, t1;
+        std::vector<int> mm;
+        bowMatcher.SearchByBoW(F1, goodKF, fvKF, F2, k2, fvF, mm);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int i = 0; i < 20; ++i) bowMatcher.SearchByBoW(F1, goodKF, fvKF, F2, k2, fvF, mm);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        printf("SearchByBoW %zu x %zu features, %zu / %zu nodes: %.0f us per call\n", k1.size(), k2.size(), fvKF.size(), fvF.size(),
+               ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 20e3);
+    }
     printf("dropin ok: %zu / %zu keypoints, %d initial matches\n", k1.size(), k2.size(), nm);
     return 0;
 }

@@ -106,6 +106,16 @@ struct FrameGrid {
 int csr_distances(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
                   const int32_t* rowptr, const int32_t* cand, int32_t* dist_out);
 
+// One windowed search: Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cc:327-380); r < 0 asks for nothing.
+struct WindowQuery { float x, y, r; int16_t minLevel, maxLevel; };
+// Candidate lists and distances of nq windowed searches, on the device: row i of the CSR holds, in the order the
+// reference's grid walk visits them (grid_order = the frame grid's cell_items: cells column by column, insertion order
+// inside a cell), the keypoints of k2 inside query i's window and level band, with the Hamming distance between
+// qdesc[i] and their descriptor.  Defined in orbx_match.hip.
+int window_csr(orbx_matcher* m, const WindowQuery* q, const uint8_t* qdesc, int nq,
+               const orbx_keypoint* k2, const uint8_t* d2, int n2, const int* grid_order, int n_in_grid,
+               std::vector<int32_t>& rowptr, std::vector<int32_t>& cand, std::vector<int32_t>& dist);
+
 // device, private stream and growable device staging buffers (slot 0..7) of a matcher context (orbx_match.hip)
 int matcher_device(const orbx_matcher* m);
 void* matcher_stream(const orbx_matcher* m);

@@ -246,6 +246,82 @@ __global__ __launch_bounds__(kStereoThreads) void k_stereo(const orbx_keypoint* 
     }
 }
 
+// Windowed candidate generation on the device.  One wavefront per query walks the keypoints in grid order, 64 at a time:
+// a keypoint is a candidate when it lies strictly inside the square window and passes the level filter (for keypoints that
+// are in the grid this is exactly the set the reference's walk over the covered cells returns, and ballot compaction keeps
+// the walk's order).  First launch counts, a one-workgroup scan turns counts into row offsets, second launch writes
+// candidate indices and distances.
+struct KpLite { float x, y; int32_t octave; };
+
+__device__ __forceinline__ bool in_window(const orbx::WindowQuery& q, const KpLite& k)
+{
+    const bool check = q.minLevel > 0 || q.maxLevel >= 0;
+    if (check && (k.octave < q.minLevel || (q.maxLevel >= 0 && k.octave > q.maxLevel))) return false;
+    return fabsf(__fsub_rn(k.x, q.x)) < q.r && fabsf(__fsub_rn(k.y, q.y)) < q.r;
+}
+
+template <bool kFill>
+__global__ __launch_bounds__(256) void k_window(const orbx::WindowQuery* __restrict__ qs, const uint32_t* __restrict__ qdesc, int nq,
+                                                const KpLite* __restrict__ kp, const uint32_t* __restrict__ d2,
+                                                const int32_t* __restrict__ order, int n_in_grid,
+                                                int32_t* __restrict__ rowptr, int32_t* __restrict__ cand, int32_t* __restrict__ dist, int cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const orbx::WindowQuery q = qs[qi];
+    uint32_t qv[8];
+    int base = 0;
+    if (kFill) {
+        base = rowptr[qi];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = qdesc[(size_t)qi * 8 + i];
+    }
+    int count = 0;
+    if (q.r >= 0.0f)
+        for (int j0 = 0; j0 < n_in_grid; j0 += 64) {
+            const int j = j0 + lane;
+            int idx = -1;
+            bool on = false;
+            if (j < n_in_grid) { idx = order[j]; on = in_window(q, kp[idx]); }
+            const unsigned long long mask = __ballot(on);
+            if (kFill && on) {
+                const int pos = base + count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (pos < cap) {
+                    const uint4* tp = reinterpret_cast<const uint4*>(d2 + (size_t)idx * 8);
+                    const uint4 lo = tp[0], hi = tp[1];
+                    cand[pos] = idx;
+                    dist[pos] = __popc(qv[0] ^ lo.x) + __popc(qv[1] ^ lo.y) + __popc(qv[2] ^ lo.z) + __popc(qv[3] ^ lo.w) +
+                                __popc(qv[4] ^ hi.x) + __popc(qv[5] ^ hi.y) + __popc(qv[6] ^ hi.z) + __popc(qv[7] ^ hi.w);
+                }
+            }
+            count += __popcll(mask);
+        }
+    if (!kFill && lane == 0) rowptr[qi] = count;
+}
+
+// exclusive prefix sum of nq counts in place, total in rowptr[nq]; one workgroup
+__global__ __launch_bounds__(1024) void k_window_scan(int32_t* __restrict__ rowptr, int nq)
+{
+    __shared__ int32_t s_part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (nq + 1023) / 1024;
+    const int c0 = min(tid * chunk, nq), c1 = min(c0 + chunk, nq);
+    int sum = 0;
+    for (int i = c0; i < c1; ++i) sum += rowptr[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = tid >= d ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int i = c0; i < c1; ++i) { const int c = rowptr[i]; rowptr[i] = run; run += c; }
+    if (tid == 1023) rowptr[nq] = s_part[1023];
+}
+
 // rows a right keypoint's band can span: ceil(y + r) - floor(y - r) + 1 <= 2r + 3 with r = 2 * scale
 static int stereo_band_rows(const float* scale_factors, int nlevels)
 {
@@ -262,6 +338,8 @@ struct orbx_matcher {
     hipStream_t stream = nullptr;
     void* ws = nullptr; size_t ws_bytes = 0;       // partial results of the brute-force kernel
     void* stage[8] = {}; size_t stage_bytes[8] = {}; // staging buffers of the host entry points
+    void* win = nullptr; size_t win_bytes = 0;       // device arena of the windowed candidate generation
+    uint8_t* pin = nullptr; size_t pin_bytes = 0;    // pinned host mirror of it (one upload, two small downloads per call)
 };
 
 static int reserve(void** p, size_t* have, size_t need)
@@ -310,6 +388,8 @@ void orbx_matcher_destroy(orbx_matcher* m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->ws) (void)hipFree(m->ws);
     for (void* p : m->stage) if (p) (void)hipFree(p);
+    if (m->win) (void)hipFree(m->win);
+    if (m->pin) (void)hipHostFree(m->pin);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -472,6 +552,71 @@ namespace orbx {
 int csr_distances(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, const int32_t* rowptr, const int32_t* cand, int32_t* dist_out)
 {
     return orbx_hamming_csr(m, q, nq, t, nt, rowptr, cand, dist_out);
+}
+int window_csr(orbx_matcher* m, const WindowQuery* q, const uint8_t* qdesc, int nq, const orbx_keypoint* k2, const uint8_t* d2, int n2,
+               const int* grid_order, int n_in_grid, std::vector<int32_t>& rowptr, std::vector<int32_t>& cand, std::vector<int32_t>& dist)
+{
+    rowptr.assign((size_t)nq + 1, 0); cand.clear(); dist.clear();
+    if (nq == 0 || n2 == 0 || n_in_grid == 0) return ORBX_OK;
+    HIP_CHECK(hipSetDevice(m->device));
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // arena: [queries | query descriptors | keypoints | descriptors | grid order | rowptr | cand | dist]
+    const size_t o_q = 0, o_qd = o_q + up(sizeof(WindowQuery) * nq), o_kp = o_qd + up((size_t)nq * 32), o_d2 = o_kp + up(sizeof(KpLite) * n2),
+                 o_ord = o_d2 + up((size_t)n2 * 32), o_row = o_ord + up(sizeof(int32_t) * n_in_grid), o_out = o_row + up(sizeof(int32_t) * (nq + 1));
+    size_t cap = std::max<size_t>((size_t)64 * nq, 1 << 16);      // candidate capacity; grown when a call needs more
+    bool filled = false;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const size_t need = o_out + up(sizeof(int32_t) * cap) * 2;
+        if (m->win_bytes < need) {
+            filled = false;
+            if (m->win) (void)hipFree(m->win);
+            if (m->pin) (void)hipHostFree(m->pin);
+            m->win = nullptr; m->pin = nullptr; m->win_bytes = m->pin_bytes = 0;
+            HIP_CHECK(hipMalloc(&m->win, need));
+            HIP_CHECK(hipHostMalloc((void**)&m->pin, need, hipHostMallocDefault));
+            m->win_bytes = m->pin_bytes = need;
+        }
+        uint8_t* h = m->pin; uint8_t* d = static_cast<uint8_t*>(m->win);
+        if (!filled) {
+            filled = true;
+            std::memcpy(h + o_q, q, sizeof(WindowQuery) * nq);
+            std::memcpy(h + o_qd, qdesc, (size_t)nq * 32);
+            KpLite* kl = reinterpret_cast<KpLite*>(h + o_kp);
+            for (int i = 0; i < n2; ++i) { kl[i].x = k2[i].x; kl[i].y = k2[i].y; kl[i].octave = k2[i].octave; }
+            std::memcpy(h + o_d2, d2, (size_t)n2 * 32);
+            std::memcpy(h + o_ord, grid_order, sizeof(int32_t) * n_in_grid);
+        }
+        HIP_CHECK(hipMemcpyAsync(d, h, o_row, hipMemcpyHostToDevice, m->stream));
+        const dim3 grid((nq + 3) / 4), block(256);
+        int32_t* d_row = reinterpret_cast<int32_t*>(d + o_row);
+        int32_t* d_cand = reinterpret_cast<int32_t*>(d + o_out);
+        int32_t* d_dist = reinterpret_cast<int32_t*>(d + o_out + up(sizeof(int32_t) * cap));
+        hipLaunchKernelGGL(k_window<false>, grid, block, 0, m->stream, reinterpret_cast<const WindowQuery*>(d + o_q), reinterpret_cast<const uint32_t*>(d + o_qd), nq,
+                           reinterpret_cast<const KpLite*>(d + o_kp), reinterpret_cast<const uint32_t*>(d + o_d2), reinterpret_cast<const int32_t*>(d + o_ord),
+                           n_in_grid, d_row, d_cand, d_dist, (int)cap);
+        hipLaunchKernelGGL(k_window_scan, dim3(1), dim3(1024), 0, m->stream, d_row, nq);
+        hipLaunchKernelGGL(k_window<true>, grid, block, 0, m->stream, reinterpret_cast<const WindowQuery*>(d + o_q), reinterpret_cast<const uint32_t*>(d + o_qd), nq,
+                           reinterpret_cast<const KpLite*>(d + o_kp), reinterpret_cast<const uint32_t*>(d + o_d2), reinterpret_cast<const int32_t*>(d + o_ord),
+                           n_in_grid, d_row, d_cand, d_dist, (int)cap);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(h + o_row, d_row, sizeof(int32_t) * (nq + 1), hipMemcpyDeviceToHost, m->stream));
+        HIP_CHECK(hipStreamSynchronize(m->stream));
+        const int32_t* hrow = reinterpret_cast<const int32_t*>(h + o_row);
+        const size_t total = (size_t)hrow[nq];
+        if (total > cap) { cap = total; continue; }               // rare: rerun with room for every candidate
+        rowptr.assign(hrow, hrow + nq + 1);
+        if (total) {
+            HIP_CHECK(hipMemcpyAsync(h + o_out, d_cand, sizeof(int32_t) * total, hipMemcpyDeviceToHost, m->stream));
+            HIP_CHECK(hipMemcpyAsync(h + o_out + up(sizeof(int32_t) * cap), d_dist, sizeof(int32_t) * total, hipMemcpyDeviceToHost, m->stream));
+            HIP_CHECK(hipStreamSynchronize(m->stream));
+            const int32_t* hc = reinterpret_cast<const int32_t*>(h + o_out);
+            const int32_t* hd = reinterpret_cast<const int32_t*>(h + o_out + up(sizeof(int32_t) * cap));
+            cand.assign(hc, hc + total); dist.assign(hd, hd + total);
+        }
+        return ORBX_OK;
+    }
+    set_error("window_csr: candidate capacity");
+    return ORBX_ERR_CAPACITY;
 }
 int matcher_device(const orbx_matcher* m) { return m->device; }
 void* matcher_stream(const orbx_matcher* m) { return m->stream; }

@@ -36,6 +36,18 @@ struct Csr {
         dist.assign(cand.size(), 0);
         return csr_distances(m, q, nq, t, nt, rowptr.data(), cand.data(), dist.data());
     }
+    // windowed searches: the frame grid is built here (its cell_items is the order the reference's walk visits keypoints
+    // in), the windows are evaluated and the distances computed on the device
+    std::vector<WindowQuery> wq;
+    void window(float x, float y, float r, int minLevel, int maxLevel) { wq.push_back(WindowQuery{x, y, r, (int16_t)minLevel, (int16_t)maxLevel}); }
+    void window_none() { wq.push_back(WindowQuery{0.f, 0.f, -1.f, 0, 0}); }
+    int run_windows(orbx_matcher* m, const uint8_t* qdesc, const orbx_keypoint* k2, const uint8_t* d2, int n2,
+                    float minX, float maxX, float minY, float maxY)
+    {
+        FrameGrid grid;
+        grid.build(k2, n2, minX, maxX, minY, maxY);
+        return window_csr(m, wq.data(), qdesc, (int)wq.size(), k2, d2, n2, grid.cell_items.data(), grid.cell_start.back(), rowptr, cand, dist);
+    }
 };
 
 bool octaves_ok(const orbx_keypoint* k, int n)
@@ -59,18 +71,13 @@ int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* k1, con
     *nmatches = 0;
     for (int i = 0; i < n1; ++i) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return ORBX_OK;
-    FrameGrid grid;
-    grid.build(k2, n2, minX, maxX, minY, maxY);
     Csr csr;
-    csr.start(n1);
-    std::vector<int> v;
     for (int i1 = 0; i1 < n1; ++i1) {
         const int level1 = k1[i1].octave;
-        if (level1 > 0) { csr.push_empty(); continue; }
-        grid.query(prev_matched_xy[2 * i1], prev_matched_xy[2 * i1 + 1], (float)window, level1, level1, v);
-        csr.push_row(v);
+        if (level1 > 0) { csr.window_none(); continue; }
+        csr.window(prev_matched_xy[2 * i1], prev_matched_xy[2 * i1 + 1], (float)window, level1, level1);
     }
-    int rc = csr.run(m, d1, n1, d2, n2);
+    int rc = csr.run_windows(m, d1, k2, d2, n2, minX, maxX, minY, maxY);
     if (rc) return rc;
 
     int count = 0;
@@ -125,16 +132,9 @@ int orbx_search_by_projection_mappoints(orbx_matcher* m, const float* qu, const 
     if (nq == 0 || n2 == 0) return ORBX_OK;
     if (!qu || !qv || !qr || !qlevel || !qdesc || !k2 || !d2 || !claimed || (uright2 && !qur)) { set_error("orbx_search_by_projection_mappoints: null pointer"); return ORBX_ERR_BAD_ARG; }
     if (!octaves_ok(k2, n2)) { set_error("octave out of range"); return ORBX_ERR_BAD_ARG; }
-    FrameGrid grid;
-    grid.build(k2, n2, minX, maxX, minY, maxY);
     Csr csr;
-    csr.start(nq);
-    std::vector<int> v;
-    for (int i = 0; i < nq; ++i) {
-        grid.query(qu[i], qv[i], qr[i], qlevel[i] - 1, qlevel[i], v);
-        csr.push_row(v);
-    }
-    int rc = csr.run(m, qdesc, nq, d2, n2);
+    for (int i = 0; i < nq; ++i) csr.window(qu[i], qv[i], qr[i], qlevel[i] - 1, qlevel[i]);
+    int rc = csr.run_windows(m, qdesc, k2, d2, n2, minX, maxX, minY, maxY);
     if (rc) return rc;
     int count = 0;
     for (int i = 0; i < nq; ++i) {
@@ -173,19 +173,14 @@ int orbx_search_by_projection_lastframe(orbx_matcher* m, const float* qu, const 
     *nmatches = 0;
     if (nq == 0 || n2 == 0) return ORBX_OK;
     if (!qu || !qv || !qradius || !qoctave || !qdesc || !k2 || !d2 || !claimed || (uright2 && !qur) || (check_ori && !qangle)) { set_error("orbx_search_by_projection_lastframe: null pointer"); return ORBX_ERR_BAD_ARG; }
-    FrameGrid grid;
-    grid.build(k2, n2, minX, maxX, minY, maxY);
     Csr csr;
-    csr.start(nq);
-    std::vector<int> v;
     for (int i = 0; i < nq; ++i) {
         const int o = qoctave[i];
-        if (mode == 1) grid.query(qu[i], qv[i], qradius[i], o, -1, v);
-        else if (mode == 2) grid.query(qu[i], qv[i], qradius[i], 0, o, v);
-        else grid.query(qu[i], qv[i], qradius[i], o - 1, o + 1, v);
-        csr.push_row(v);
+        if (mode == 1) csr.window(qu[i], qv[i], qradius[i], o, -1);
+        else if (mode == 2) csr.window(qu[i], qv[i], qradius[i], 0, o);
+        else csr.window(qu[i], qv[i], qradius[i], o - 1, o + 1);
     }
-    int rc = csr.run(m, qdesc, nq, d2, n2);
+    int rc = csr.run_windows(m, qdesc, k2, d2, n2, minX, maxX, minY, maxY);
     if (rc) return rc;
     int count = 0;
     std::vector<int> hist[HISTO_LENGTH];
@@ -286,17 +281,12 @@ static int project_best1(orbx_matcher* m, const float* qu, const float* qv, cons
                          const float* qur, const float* uright2, const float* inv_level_sigma2,
                          int32_t* best_idx, int32_t* best_dist)
 {
-    FrameGrid grid;
-    grid.build(k2, n2, minX, maxX, minY, maxY);
     Csr csr;
-    csr.start(nq);
-    std::vector<int> v;
     for (int i = 0; i < nq; ++i) {
-        v.clear();
-        if (!qvalid || qvalid[i]) grid.query(qu[i], qv[i], qradius[i], qlevel[i] - 1, qlevel[i], v);   // GetFeaturesInArea + the level test
-        csr.push_row(v);
+        if (!qvalid || qvalid[i]) csr.window(qu[i], qv[i], qradius[i], qlevel[i] - 1, qlevel[i]);     // GetFeaturesInArea + the level test
+        else csr.window_none();
     }
-    int rc = csr.run(m, qdesc, nq, d2, n2);
+    int rc = csr.run_windows(m, qdesc, k2, d2, n2, minX, maxX, minY, maxY);
     if (rc) return rc;
     for (int i = 0; i < nq; ++i) {
         int bestDist = 0x7FFFFFFF, bestIdx = -1;
@@ -389,18 +379,11 @@ int orbx_search_by_projection_keyframe(orbx_matcher* m, const float* qu, const f
     if (nq == 0 || n2 == 0) return ORBX_OK;
     if (!qu || !qv || !qradius || !qlevel || !qdesc || !k2 || !d2 || !claimed) { set_error("orbx_search_by_projection_keyframe: null pointer"); return ORBX_ERR_BAD_ARG; }
     if (!octaves_ok(k2, n2)) { set_error("octave out of range"); return ORBX_ERR_BAD_ARG; }
-    FrameGrid grid;
-    grid.build(k2, n2, minX, maxX, minY, maxY);
     Csr csr;
-    csr.start(nq);
-    std::vector<int> v;
-    for (int i = 0; i < nq; ++i) {
-        // GetFeaturesInArea(u, v, radius) and the level test of the loop (:365, :381-384) visit the same features in the
-        // same order as the level-filtered grid query
-        grid.query(qu[i], qv[i], qradius[i], qlevel[i] - 1, qlevel[i], v);
-        csr.push_row(v);
-    }
-    int rc = csr.run(m, qdesc, nq, d2, n2);
+    // GetFeaturesInArea(u, v, radius) and the level test of the loop (:365, :381-384) visit the same features in the
+    // same order as the level-filtered window
+    for (int i = 0; i < nq; ++i) csr.window(qu[i], qv[i], qradius[i], qlevel[i] - 1, qlevel[i]);
+    int rc = csr.run_windows(m, qdesc, k2, d2, n2, minX, maxX, minY, maxY);
     if (rc) return rc;
     int count = 0;
     for (int i = 0; i < nq; ++i) {
