@@ -115,6 +115,9 @@ int orbx_undistort_points(orbx_extractor* ex, const orbx_camera* cam, const floa
 /* mvImagePyramid[level] of frame `frame` of the last batch (include/ORBextractor.h:150): the padded
  * (w+38) x (h+38) buffer is copied to dst (host); the image ROI starts at row 19, column 19. */
 int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride);
+/* All levels of one frame in one round trip (what ORBextractor::operator() needs to refill mvImagePyramid):
+ * dst[l] / dst_stride[l] as for orbx_pyramid_level. */
+int orbx_pyramid_levels(orbx_extractor* ex, int frame, uint8_t* const* dst, const ptrdiff_t* dst_stride);
 /* Device view of the same level: pointer to the ROI origin and its row stride.  The batch path fills the
  * 3 innermost pixels of the REFLECT_101 frame (all any stage reads); orbx_pyramid_level completes the
  * 19-pixel frame of the level it copies. */

@@ -44,6 +44,8 @@ def test_stage_parity(vsa, oracle, cfg):
         want = oex.level_padded(l)
         assert got.shape == want.shape, l
         assert np.array_equal(got, want), f"pyramid level {l}: {np.count_nonzero(got != want)} pixels differ"
+    for l, got in enumerate(ex.pyramid_levels(0)):                       # the one-trip form of the same download
+        assert np.array_equal(got, oex.level_padded(l)), f"pyramid level {l} (batched download)"
     for l in range(nl):
         got, want = ex.debug_blurred_level(0, l), oex.level_blurred(l)
         assert want is None or np.array_equal(got, want), f"blurred level {l}: {np.count_nonzero(got != want)} pixels differ"

@@ -69,6 +69,7 @@ _SIGS = {
     "orbx_extract_batch": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i, _vp]),
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _pd]),
+    "orbx_pyramid_levels": (_i, [_vp, _i, _vp, _vp]),
     "orbx_pyramid_level_device": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd)]),
     "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _pd]),
     "orbx_search_by_projection_keyframe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, C.POINTER(_i)]),
@@ -297,6 +298,17 @@ class Extractor:
         out = np.zeros((h + 38, w + 38), np.uint8)
         _check(lib.orbx_pyramid_level(self.h, frame, level, _ptr(out), out.strides[0]))
         return out
+
+    def pyramid_levels(self, frame):
+        """Every padded level of one frame in one round trip."""
+        outs = []
+        for l in range(self.params.nlevels):
+            w, h = level_size(self.params, self.width, self.height, l)
+            outs.append(np.zeros((h + 38, w + 38), np.uint8))
+        ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        strides = (C.c_ssize_t * len(outs))(*[o.strides[0] for o in outs])
+        _check(lib.orbx_pyramid_levels(self.h, frame, ptrs, strides))
+        return outs
 
     def stereo_refine(self, right, kl, kr, best_dist, best_idx, bf, min_d, max_d):
         """Sub-pixel part of Frame::ComputeStereoMatches on this (left) and `right` extractor's last frame 0."""

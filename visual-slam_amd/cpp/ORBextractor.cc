@@ -115,13 +115,18 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     }
 
     if (mbDownloadPyramid) {
+        std::vector<cv::Mat> padded(nlevels);
+        std::vector<uint8_t*> ptrs(nlevels);
+        std::vector<ptrdiff_t> strides(nlevels);
+        std::vector<int> ws(nlevels), hs(nlevels);
         for (int level = 0; level < nlevels; ++level) {
-            int w = 0, h = 0;
-            check(orbx_level_size(&mParams, width, image.rows, level, &w, &h), "ORBextractor: level size");
-            cv::Mat temp(h + 38, w + 38, CV_8UC1);
-            check(orbx_pyramid_level(mpContext, 0, level, temp.ptr(), (ptrdiff_t)temp.step), "ORBextractor: pyramid");
-            mvImagePyramid[level] = temp(cv::Rect(19, 19, w, h));
+            check(orbx_level_size(&mParams, width, image.rows, level, &ws[level], &hs[level]), "ORBextractor: level size");
+            padded[level] = cv::Mat(hs[level] + 38, ws[level] + 38, CV_8UC1);
+            ptrs[level] = padded[level].ptr(); strides[level] = (ptrdiff_t)padded[level].step;
         }
+        check(orbx_pyramid_levels(mpContext, 0, ptrs.data(), strides.data()), "ORBextractor: pyramid");
+        for (int level = 0; level < nlevels; ++level)
+            mvImagePyramid[level] = padded[level](cv::Rect(19, 19, ws[level], hs[level]));     // an ROI of the padded buffer, as in the reference
     }
 }
 

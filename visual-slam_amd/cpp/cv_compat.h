@@ -42,8 +42,9 @@ public:
     void create(int r, int c, int /*type*/)
     {
         if (r == rows && c == cols && owner_ && step == (size_t)c) return;
-        owner_ = std::make_shared<std::vector<uint8_t>>((size_t)r * c);
-        rows = r; cols = c; step = (size_t)c; data = owner_->data();
+        const size_t bytes = (size_t)r * (size_t)c;
+        owner_ = std::shared_ptr<uint8_t>(new uint8_t[bytes > 0 ? bytes : 1], std::default_delete<uint8_t[]>());   // uninitialised, as cv::Mat::create leaves it
+        rows = r; cols = c; step = (size_t)c; data = owner_.get();
     }
     void release() { owner_.reset(); rows = cols = 0; step = 0; data = nullptr; }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
@@ -71,7 +72,7 @@ public:
         return m;
     }
 private:
-    std::shared_ptr<std::vector<uint8_t>> owner_;
+    std::shared_ptr<uint8_t> owner_;
 };
 
 typedef const Mat& InputArray;

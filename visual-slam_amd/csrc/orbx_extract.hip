@@ -1728,6 +1728,33 @@ int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, p
     return ORBX_OK;
 }
 
+int orbx_pyramid_levels(orbx_extractor* ex, int frame, uint8_t* const* dst, const ptrdiff_t* dst_stride)
+{
+    if (!ex || !dst || !dst_stride || frame < 0 || frame >= ex->max_batch) return ORBX_ERR_BAD_ARG;
+    const Geometry& G = ex->geo;
+    for (int l = 0; l < G.nlevels; ++l)
+        if (!dst[l] || dst_stride[l] < G.lv[l].w + 2 * kEdge) return ORBX_ERR_BAD_ARG;
+    HIP_CHECK(hipSetDevice(ex->device));
+    // complete the 19-pixel frames of every level in one launch, then one copy of the frame's whole pyramid block
+    hipLaunchKernelGGL(k_borders, dim3((ex->hlv[0].border_threads + 255) / 256, G.nlevels, 1), dim3(256), 0, ex->stream,
+                       ex->d_pyr + (size_t)frame * G.pyr_bytes, 0ull, ex->d_lv, kEdge, 8, 1 << 20);
+    HIP_CHECK(hipGetLastError());
+    if (ex->h_level_bytes < G.pyr_bytes) {
+        if (ex->h_level) (void)hipHostFree(ex->h_level);
+        ex->h_level = nullptr; ex->h_level_bytes = 0;
+        HIP_CHECK(hipHostMalloc(&ex->h_level, G.pyr_bytes, hipHostMallocDefault));
+        ex->h_level_bytes = G.pyr_bytes;
+    }
+    HIP_CHECK(hipMemcpyAsync(ex->h_level, ex->d_pyr + (size_t)frame * G.pyr_bytes, G.pyr_bytes, hipMemcpyDeviceToHost, ex->stream));
+    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    for (int l = 0; l < G.nlevels; ++l) {
+        const LevelGeom& L = G.lv[l];
+        for (int y = 0; y < L.rows; ++y)
+            std::memcpy(dst[l] + (size_t)y * dst_stride[l], ex->h_level + L.offset + (size_t)y * L.stride + (kRoiX - kEdge), (size_t)L.w + 2 * kEdge);
+    }
+    return ORBX_OK;
+}
+
 int orbx_stereo_refine_batch_device(orbx_extractor* left, orbx_extractor* right,
                                     const orbx_keypoint* d_kl, const int32_t* d_nl, const orbx_keypoint* d_kr, int cap_per_frame,
                                     int n_pairs, const int32_t* d_best_dist, const int32_t* d_best_idx, float bf, float min_d,
