@@ -297,3 +297,40 @@ def test_full_size_batch_kitti_shape(vsa, oracle):
         assert np.array_equal(desc[B - U + f, :n].cpu().numpy(), od)
         assert np.array_equal(kps[B - U + f, :n].cpu().numpy().view(vsa.KEYPOINT_DTYPE).reshape(n), ok.astype(vsa.KEYPOINT_DTYPE))
     ex.close()
+
+
+def test_error_paths(vsa, oracle):
+    """Status codes instead of faults: output capacity too small (the first `cap` keypoints are still returned and the
+    count reports how many there were), bad batch sizes and strides, wrong input layout."""
+    import ctypes as C
+    w, h = 320, 240
+    img = vsa.synth_frame(5, w, h)
+    ex = vsa.Extractor(vsa.make_params(500, 1.2, 4), w, h, max_batch=2, device=0)
+    okps, odesc = oracle.Extractor(oracle.make_params(500, 1.2, 4)).extract(img)
+    cap = 100
+    kps = np.zeros(cap, vsa.KEYPOINT_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
+    st = vsa.lib.orbx_extract(ex.h, img.ctypes.data_as(C.c_void_p), w, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    assert st == 4 and n.value == len(okps) > cap                                  # ORBX_ERR_CAPACITY
+    assert np.array_equal(desc, odesc[:cap]) and np.array_equal(kps, okps[:cap].astype(vsa.KEYPOINT_DTYPE))
+    with pytest.raises(vsa.OrbxError) as e:
+        ex.extract_batch(np.stack([img, img, img]))                                # more frames than max_batch
+    assert e.value.status == 1
+    counts = np.zeros(1, np.int32)
+    st = vsa.lib.orbx_extract_batch(ex.h, img.ctypes.data_as(C.c_void_p), w - 1, w * h, 1, kps.ctypes.data_as(C.c_void_p),
+                                    desc.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), cap)
+    assert st == 1                                                                 # row stride below the width
+    with pytest.raises(vsa.OrbxError):
+        vsa.lib.orbx_extractor_set_input_format.restype = C.c_int
+        vsa._check(vsa.lib.orbx_extractor_set_input_format(ex.h, 9))
+    k2, d2 = ex.extract(img)                                                       # the context is still usable
+    assert np.array_equal(d2, odesc)
+    # a null image is the reference's empty-image early return: success, nothing written
+    st = vsa.lib.orbx_extract(ex.h, None, w, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    assert st == 0 and n.value == 0
+    ex.close()
+    m = vsa.Matcher(device=0)
+    with pytest.raises(vsa.OrbxError):
+        m.hamming_csr(odesc[:4], odesc, np.array([0, 2, 1, 3, 3], np.int32), np.array([0, 1, 2], np.int32))   # rowptr not monotone
+    with pytest.raises(vsa.OrbxError):
+        m.hamming_csr(odesc[:2], odesc[:10], np.array([0, 1, 2], np.int32), np.array([3, 10], np.int32))      # candidate out of range
+    m.close()
