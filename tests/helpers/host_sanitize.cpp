@@ -1,0 +1,120 @@
+// Host-only logic of liborbx under AddressSanitizer + UndefinedBehaviorSanitizer (no device needed): the geometry builder
+// over random and extreme image shapes, the frame grid with hostile coordinates, the archive records, the synthetic
+// generators and the small host helpers.  Exits non-zero on a failed expectation; the sanitizers abort on a finding.
+#include "../../visual-slam_amd/csrc/orbx_internal.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+
+using namespace orbx;
+
+static int fails = 0;
+#define EXPECT(c) do { if (!(c)) { std::fprintf(stderr, "line %d: %s\n", __LINE__, #c); ++fails; } } while (0)
+
+int main()
+{
+    std::mt19937 rng(7);
+    auto uni = [&](int a, int b) { return (int)(rng() % (unsigned)(b - a + 1)) + a; };
+    // geometry builder: random shapes, every table it emits must stay inside the buffers it describes
+    int accepted = 0;
+    for (int it = 0; it < 3000; ++it) {
+        orbx_params p;
+        p.nfeatures = uni(1, 9000); p.nlevels = uni(1, 14);
+        const float sfs[] = {1.05f, 1.1f, 1.2f, 1.25f, 1.3f, 1.5f, 2.0f, 3.0f};
+        p.scale_factor = sfs[uni(0, 7)];
+        p.ini_th_fast = uni(1, 60); p.min_th_fast = uni(1, p.ini_th_fast); p.blur_rounding = uni(0, 1);
+        const int w = it % 50 == 0 ? uni(1, 9000) : uni(40, 2200), h = it % 50 == 1 ? uni(1, 9000) : uni(40, 1400);
+        Geometry g;
+        const int rc = build_geometry(p, w, h, g);
+        if (rc != ORBX_OK) { EXPECT(rc == ORBX_ERR_UNSUPPORTED_GEOMETRY || rc == ORBX_ERR_BAD_ARG); continue; }
+        ++accepted;
+        EXPECT((int)g.lv.size() == p.nlevels);
+        size_t end = 0;
+        for (const LevelGeom& L : g.lv) {
+            EXPECT(L.offset >= end);
+            EXPECT(L.roi == L.offset + (size_t)kEdge * L.stride + kRoiX);
+            EXPECT(L.stride >= kRoiX + L.w + kEdge && L.rows == L.h + 2 * kEdge);
+            end = L.offset + (size_t)L.stride * L.rows;
+            EXPECT(L.cell_first >= 0 && L.cell_first + L.cell_count <= (int)g.cells.size());
+            for (int c = L.cell_first; c < L.cell_first + L.cell_count; ++c) {
+                const CellRec& cr = g.cells[c];
+                EXPECT(cr.x0 >= 0 && cr.y0 >= 0 && cr.x0 + cr.cw + 6 <= L.w && cr.y0 + cr.ch + 6 <= L.h);
+                EXPECT(cr.slot >= 0 && cr.slot + cr.cap <= L.cand_cap);
+            }
+            EXPECT(L.kp_offset + L.kp_cap <= g.kp_total);
+        }
+        EXPECT(end <= g.pyr_bytes);
+        int w2, h2;
+        EXPECT(orbx_level_size(&p, w, h, p.nlevels - 1, &w2, &h2) == ORBX_OK && w2 == g.lv.back().w && h2 == g.lv.back().h);
+        EXPECT(orbx_keypoint_capacity(&p, w, h) == g.out_cap);
+    }
+    EXPECT(accepted > 500);
+    // frame grid: hostile coordinates must neither crash nor appear as candidates
+    {
+        const int n = 3000;
+        std::vector<orbx_keypoint> k(n);
+        const float inf = std::numeric_limits<float>::infinity(), nan = std::numeric_limits<float>::quiet_NaN();
+        for (int i = 0; i < n; ++i) {
+            k[i] = orbx_keypoint{(float)uni(-50, 700), (float)uni(-50, 530), 31.f, 0.f, 20.f, uni(0, 7), -1};
+            if (i % 97 == 0) k[i].x = nan;
+            if (i % 101 == 0) k[i].y = inf;
+            if (i % 103 == 0) k[i].x = -3e9f;
+        }
+        orbx_frame_grid* grid = nullptr;
+        EXPECT(orbx_grid_create(k.data(), n, 0.f, 640.f, 0.f, 480.f, &grid) == ORBX_OK);
+        std::vector<int32_t> out(n);
+        for (int q = 0; q < 2000; ++q) {
+            const float x = (float)uni(-200, 900), y = (float)uni(-200, 700), r = q % 40 == 0 ? 1e9f : (float)uni(0, 150);
+            int cnt = 0;
+            EXPECT(orbx_grid_features_in_area(grid, x, y, r, q % 3 ? -1 : uni(0, 7), q % 5 ? -1 : uni(0, 7), out.data(), n, &cnt) == ORBX_OK);
+            for (int c = 0; c < cnt; ++c) {
+                const orbx_keypoint& kp = k[out[c]];
+                EXPECT(std::fabs(kp.x - x) < r && std::fabs(kp.y - y) < r);
+            }
+        }
+        int cnt = -1;
+        EXPECT(orbx_grid_features_in_area(grid, nan, 5.f, 10.f, -1, -1, out.data(), n, &cnt) == ORBX_OK && cnt == 0);
+        orbx_grid_destroy(grid);
+    }
+    // archive records
+    {
+        std::vector<uint8_t> desc(50 * 32), rec(24 + desc.size());
+        for (size_t i = 0; i < desc.size(); ++i) desc[i] = (uint8_t)(i * 7);
+        EXPECT(orbx_mat_record_write(desc.data(), 50, 32, 1, 0, rec.data(), (int64_t)rec.size() - 1) == -1);
+        EXPECT(orbx_mat_record_write(desc.data(), 50, 32, 1, 0, rec.data(), (int64_t)rec.size()) == (int64_t)rec.size());
+        int r, c, es, et; const uint8_t* d;
+        for (int64_t len = 0; len < (int64_t)rec.size(); len += 13) EXPECT(orbx_mat_record_read(rec.data(), len, &r, &c, &es, &et, &d) == -1);
+        EXPECT(orbx_mat_record_read(rec.data(), (int64_t)rec.size(), &r, &c, &es, &et, &d) == (int64_t)rec.size() && r == 50 && c == 32 && !std::memcmp(d, desc.data(), desc.size()));
+        std::memset(rec.data(), 0xFF, 24);
+        EXPECT(orbx_mat_record_read(rec.data(), (int64_t)rec.size(), &r, &c, &es, &et, &d) == -1);
+    }
+    // synthetic generators and small helpers
+    {
+        std::vector<uint8_t> img(333 * 77), l(97 * 61), rgt(97 * 61);
+        orbx_synth_frame(3, 333, 77, img.data(), 333);
+        orbx_synth_stereo(4, 97, 61, l.data(), rgt.data(), 97);
+        std::vector<uint8_t> tab(1000 * 32), q(64 * 32); std::vector<int64_t> src(64);
+        orbx_synth_descriptors(42, 1000, tab.data());
+        orbx_synth_queries(43, tab.data(), 1000, 64, q.data(), src.data());
+        for (int i = 0; i < 64; ++i) EXPECT(src[i] >= 0 && src[i] < 1000 && orbx_descriptor_distance(q.data() + i * 32, tab.data() + src[i] * 32) < 60);
+        const int n = orbx_synth_vocabulary(1, 3, 4, nullptr, nullptr, nullptr, nullptr);
+        EXPECT(n == 121);
+        std::vector<int32_t> parent(n); std::vector<uint8_t> leaf(n), vd((size_t)n * 32); std::vector<double> wt(n);
+        EXPECT(orbx_synth_vocabulary(1, 3, 4, parent.data(), leaf.data(), vd.data(), wt.data()) == n);
+        for (int i = 1; i < n; ++i) EXPECT(parent[i] >= 0 && parent[i] < i);
+        EXPECT(orbx_synth_vocabulary(1, 1, 4, nullptr, nullptr, nullptr, nullptr) == -1 && orbx_synth_vocabulary(1, 20, 10, nullptr, nullptr, nullptr, nullptr) == -1);
+        int32_t sizes[30] = {0}; int i1, i2, i3;
+        sizes[4] = 10; sizes[9] = 1; sizes[20] = 2;
+        orbx_compute_three_maxima(sizes, 30, &i1, &i2, &i3);
+        EXPECT(i1 == 4 && i2 == 20 && i3 == 9);
+        orbx_best2 parts[2 * 3] = {{5, 7, 9, 0}, {256, -1, 256, 0}, {3, 2, 3, 0}, {5, 1, 6, 0}, {10, 4, 11, 0}, {2, 9, 8, 0}}, merged[3];
+        EXPECT(orbx_best2_merge(parts, 2, 3, merged) == ORBX_OK);
+        EXPECT(merged[0].best == 5 && merged[0].best_idx == 1 && merged[0].second == 5);
+        EXPECT(merged[1].best == 10 && merged[1].best_idx == 4 && merged[1].second == 11);
+        EXPECT(merged[2].best == 2 && merged[2].best_idx == 9 && merged[2].second == 3);
+    }
+    std::printf("host_sanitize: %d geometries accepted, %d failed expectations\n", accepted, fails);
+    return fails ? 1 : 0;
+}
