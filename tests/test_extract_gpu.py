@@ -334,3 +334,28 @@ def test_error_paths(vsa, oracle):
     with pytest.raises(vsa.OrbxError):
         m.hamming_csr(odesc[:2], odesc[:10], np.array([0, 1, 2], np.int32), np.array([3, 10], np.int32))      # candidate out of range
     m.close()
+
+
+def test_host_batch_pipeline(vsa, oracle):
+    """More than eight host frames take the chunked path (pinned mirror filled by several threads, uploads overlapped with
+    the kernels of the previous chunk): 70 frames with padded rows, every frame against the oracle; then a short batch on
+    the same context."""
+    w, h, B = 331, 207, 70
+    p = vsa.make_params(400, 1.2, 5)
+    padded = np.zeros((B, h, w + 13), np.uint8)
+    for i in range(B):
+        padded[i, :, :w] = vsa.synth_frame(500 + i % 9, w, h)
+        padded[i, :, w:] = 255 - i                                         # garbage past the row end must not matter
+    ex = vsa.Extractor(p, w, h, max_batch=B, device=0)
+    cap = ex.cap
+    kps = np.zeros((B, cap), vsa.KEYPOINT_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); counts = np.zeros(B, np.int32)
+    vsa._check(vsa.lib.orbx_extract_batch(ex.h, padded.ctypes.data, padded.strides[1], padded.strides[0], B, kps.ctypes.data, desc.ctypes.data,
+                                          counts.ctypes.data, cap))
+    oex = oracle.Extractor(oracle.make_params(400, 1.2, 5))
+    want = [oex.extract(np.ascontiguousarray(padded[i, :, :w])) for i in range(9)]
+    for i in range(B):
+        ok, od = want[i % 9]
+        assert counts[i] == len(ok) and np.array_equal(desc[i, :counts[i]], od) and np.array_equal(kps[i, :counts[i]], ok.astype(vsa.KEYPOINT_DTYPE)), i
+    k2, d2, c2 = ex.extract_batch(np.ascontiguousarray(padded[3:6, :, :w]))
+    assert np.array_equal(c2, counts[3:6]) and np.array_equal(d2[1, :c2[1]], want[4][1])
+    ex.close()

@@ -5,11 +5,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 vsa = importlib.import_module("visual-slam_amd")
 w, h = 640, 480
-for B in (1, 8, 64, 256):
+for B in (1, 8, 16, 32, 64, 128, 256, 512):
     imgs = np.stack([vsa.synth_frame(i % 16, w, h) for i in range(B)])
     ex = vsa.Extractor(vsa.make_params(), w, h, max_batch=B, device=0)
     ex.extract_batch(imgs)
-    n = max(3, 200 // B)
+    n = max(10, 200 // B)
     t0 = time.perf_counter()
     for _ in range(n):
         ex.extract_batch(imgs)

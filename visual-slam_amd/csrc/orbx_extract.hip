@@ -14,6 +14,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <thread>
 #include <string>
 #include "orbx_internal.h"
 #include "octree_algo.h"
@@ -1290,6 +1291,8 @@ struct orbx_extractor {
     bool profiling = false;
 
     hipEvent_t ev[ORBX_STAGE_COUNT + 1] = {};
+    hipStream_t copy_stream = nullptr;   // uploads of the chunked host batch path
+    std::vector<hipEvent_t> chunk_ev;    // one per chunk: upload done
     float stage_ms[ORBX_STAGE_COUNT] = {};
 };
 
@@ -1300,6 +1303,21 @@ static int select_device(int device)
     if (device >= count) { set_error("device index out of range"); return ORBX_ERR_BAD_ARG; }
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
     return ORBX_OK;
+}
+
+constexpr int kHostChunk = 32;       // most frames per stage of the host batch pipeline
+constexpr int kCopyThreads = 4;      // host threads that move frames into / results out of the pinned mirrors
+
+// runs fn(begin, end) over [0, n) split into kCopyThreads contiguous parts (the calling thread takes the last one)
+template <typename F> static void parallel_rows(int n, F fn)
+{
+    const int parts = std::min(kCopyThreads, std::max(1, n / 64));
+    if (parts <= 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    th.reserve(parts - 1);
+    for (int p = 0; p + 1 < parts; ++p) th.emplace_back([=]() { fn((int)((long long)n * p / parts), (int)((long long)n * (p + 1) / parts)); });
+    fn((int)((long long)n * (parts - 1) / parts), n);
+    for (std::thread& t : th) t.join();
 }
 
 extern "C" {
@@ -1415,6 +1433,8 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
     for (auto& e : ex->ev) if (e) (void)hipEventDestroy(e);
     if (ex->graph1) (void)hipGraphExecDestroy(ex->graph1);
+    for (hipEvent_t e : ex->chunk_ev) (void)hipEventDestroy(e);
+    if (ex->copy_stream) (void)hipStreamDestroy(ex->copy_stream);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
 }
@@ -1613,14 +1633,59 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_
     if (rc) return rc;
     const Geometry& G = ex->geo;
     const size_t rbytes = (size_t)G.width * ex->channels, fbytes = rbytes * G.height;
-    for (int f = 0; f < n_frames; ++f) {
+    const bool pipelined = n_frames >= 48 && !ex->profiling;
+    for (int f = 0; f < n_frames && !pipelined; ++f) {
         const uint8_t* src = images + (ptrdiff_t)f * frame_stride;
         uint8_t* dst = ex->h_img + f * fbytes;
         if ((size_t)row_stride == rbytes) std::memcpy(dst, src, fbytes);
         else for (int y = 0; y < G.height; ++y) std::memcpy(dst + (size_t)y * rbytes, src + (ptrdiff_t)y * row_stride, rbytes);
     }
+    if (pipelined) {
+        // many frames: chunks of up to kHostChunk frames flow through a pipeline: the host copies chunk c+1 into the pinned mirror
+        // (several threads) while chunk c uploads on the copy stream and chunk c-1 runs its kernels and downloads its
+        // output slots on the compute stream
+        if (!ex->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&ex->copy_stream, hipStreamNonBlocking));
+        const int chunk = std::min(kHostChunk, std::max(16, (n_frames + 3) / 4));     // four stages when the batch allows, never tiny ones
+        const int nchunks = (n_frames + chunk - 1) / chunk;
+        while ((int)ex->chunk_ev.size() < nchunks) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ex->chunk_ev.push_back(e); }
+        for (int c = 0; c < nchunks; ++c) {
+            const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
+            parallel_rows(nf * G.height, [&](int r0, int r1) {
+                for (int r = r0; r < r1; ++r) {
+                    const int f = f0 + r / G.height, y = r % G.height;
+                    std::memcpy(ex->h_img + (size_t)f * fbytes + (size_t)y * rbytes, images + (ptrdiff_t)f * frame_stride + (ptrdiff_t)y * row_stride, rbytes);
+                }
+            });
+            HIP_CHECK(hipMemcpyAsync(ex->d_img + (size_t)f0 * fbytes, ex->h_img + (size_t)f0 * fbytes, fbytes * nf, hipMemcpyHostToDevice, ex->copy_stream));
+            HIP_CHECK(hipEventRecord(ex->chunk_ev[c], ex->copy_stream));
+            HIP_CHECK(hipStreamWaitEvent(ex->stream, ex->chunk_ev[c], 0));
+            rc = launch_frames(ex, ex->stream, f0, nf, false, ex->d_img, (ptrdiff_t)rbytes, (ptrdiff_t)fbytes, ex->d_okp, ex->d_odesc, ex->d_ocount, G.out_cap);
+            if (rc) return rc;
+            HIP_CHECK(hipMemcpyAsync(ex->h_ocount + f0, ex->d_ocount + f0, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, ex->stream));
+            HIP_CHECK(hipMemcpyAsync(ex->h_okp + (size_t)f0 * G.out_cap, ex->d_okp + (size_t)f0 * G.out_cap, sizeof(orbx_keypoint) * (size_t)G.out_cap * nf,
+                                     hipMemcpyDeviceToHost, ex->stream));
+            HIP_CHECK(hipMemcpyAsync(ex->h_odesc + (size_t)f0 * G.out_cap * 32, ex->d_odesc + (size_t)f0 * G.out_cap * 32, (size_t)32 * G.out_cap * nf,
+                                     hipMemcpyDeviceToHost, ex->stream));
+        }
+        ex->last_frames = n_frames;
+        HIP_CHECK(hipStreamSynchronize(ex->stream));
+        int status = ORBX_OK;
+        for (int f = 0; f < n_frames; ++f) {
+            counts[f] = ex->h_ocount[f];
+            if (counts[f] > cap_per_frame) { status = ORBX_ERR_CAPACITY; set_error("cap_per_frame smaller than the keypoint count"); }
+        }
+        parallel_rows(n_frames, [&](int a0, int a1) {
+            for (int f = a0; f < a1; ++f) {
+                const int n = std::min(ex->h_ocount[f], cap_per_frame);
+                if (n <= 0) continue;
+                std::memcpy(kps + (size_t)f * cap_per_frame, ex->h_okp + (size_t)f * G.out_cap, sizeof(orbx_keypoint) * n);
+                std::memcpy(desc + (size_t)f * cap_per_frame * 32, ex->h_odesc + (size_t)f * G.out_cap * 32, (size_t)32 * n);
+            }
+        });
+        return status;
+    }
     // a few frames: one round trip (counts and whole output slots together); many frames: counts first, then what is used
-    const bool one_trip = n_frames <= 8;
+    const bool one_trip = n_frames < 48;
     auto enqueue = [&]() -> int {
         HIP_CHECK(hipMemcpyAsync(ex->d_img, ex->h_img, fbytes * n_frames, hipMemcpyHostToDevice, ex->stream));
         const int r = launch_frames(ex, ex->stream, 0, n_frames, ex->profiling, ex->d_img, (ptrdiff_t)rbytes, (ptrdiff_t)fbytes, ex->d_okp, ex->d_odesc,
