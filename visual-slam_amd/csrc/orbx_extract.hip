@@ -975,15 +975,28 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     for (int q = 0; q < kKpPerWave; ++q)
         jkey[q] = jlevel[q] >= 0 ? lvlkp[(unsigned long long)frame * kp_total + lv[jlevel[q]].kp_offset + jidx[q]] : 0u;
 
-    // The loads of keypoint q+1 are issued before the arithmetic of keypoint q.
+    // Schedule: the disc loads of all four keypoints and the window loads of the first two go out first; the four
+    // orientations are then computed together, keypoint q in lane q (one pass through fastAtan2 and the double-precision
+    // sin / cos instead of four); each keypoint's 256 tests run with the window loads of the keypoint two ahead in flight.
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    struct Fetched { u32x4 w0, w1, w2, d; };
-    auto fetch = [&](int q, Fetched& f) __attribute__((always_inline)) {
+    struct Window { u32x4 w0, w1, w2; };
+    auto key_xy = [&](int q, int& kx, int& ky) __attribute__((always_inline)) {
+        kx = (int)(jkey[q] >> 20) + kMinBorder; ky = (int)((jkey[q] >> 8) & 0xFFF) + kMinBorder;
+    };
+    auto fetch_disc = [&](int q, u32x4& d) __attribute__((always_inline)) {
+        d = u32x4{0u, 0u, 0u, 0u};
+        if (jlevel[q] < 0 || !disc_lane) return;
+        const DevLevel& L = lv[jlevel[q]];
+        int kx, ky; key_xy(q, kx, ky);
+        // disc rows ky-15..ky+15 of the unblurred level, bytes kx-16..kx+15
+        const uint8_t* csrc = pyr + (unsigned long long)frame * pyr_bytes + L.roi + (long long)(ky - kHalfPatch) * L.stride + (kx - 16);
+        const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(csrc + (__umul24((uint32_t)crow, (uint32_t)L.stride) + 16u * (uint32_t)chalf));
+        d = u32x4{t.x, t.y, t.z, t.w};
+    };
+    auto fetch_window = [&](int q, Window& f) __attribute__((always_inline)) {
         if (jlevel[q] < 0) return;
         const DevLevel& L = lv[jlevel[q]];
-        const int kx = (int)(jkey[q] >> 20) + kMinBorder, ky = (int)((jkey[q] >> 8) & 0xFFF) + kMinBorder;
-        const uint32_t stride = (uint32_t)L.stride;
-        const unsigned long long fo = (unsigned long long)frame * pyr_bytes + L.roi;
+        int kx, ky; key_xy(q, kx, ky);
         // blurred window rows ky-18..ky+18, the four 16-byte columns from the one holding column kx-18, out of the
         // tiled level: tile (y >> 3, column) holds row y at byte 16 * (y & 7)
         const uint8_t* bsrc = blr + (unsigned long long)frame * blur_bytes + L.blur_offset + 128u * (uint32_t)((kx - 18) >> 4);
@@ -995,49 +1008,59 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         f.w0 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[0], wcol[0]));
         f.w1 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[1], wcol[1]));
         if (lane + 128 < kBlurW * kWinChunks) f.w2 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[2], wcol[2]));
-        // disc rows ky-15..ky+15 of the unblurred level, bytes kx-16..kx+15
-        const uint8_t* csrc = pyr + fo + (long long)(ky - kHalfPatch) * L.stride + (kx - 16);
-        if (disc_lane) {
-            const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(csrc + (__umul24((uint32_t)crow, stride) + 16u * (uint32_t)chalf));
-            f.d = u32x4{t.x, t.y, t.z, t.w};
-        }
     };
-    auto process = [&](int q, const Fetched& f) __attribute__((always_inline)) {
+    // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc, four pixels per
+    // v_dot4_u32_u8.  m10 = sum u*I = sum (u+16)*I - 16*sum I,  m01 = sum v*I; bytes outside the disc have weight 0.
+    auto moments = [&](const u32x4& d, int& m10, int& m01) __attribute__((always_inline)) {
+        uint32_t su = 0, sm = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            su = __builtin_amdgcn_udot4(d[k], cwu[k], su, false);
+            sm = __builtin_amdgcn_udot4(d[k], cwm[k], sm, false);
+        }
+        m10 = (int)su - 16 * (int)sm;                      // lanes outside the disc hold zero weights
+        m01 = cv * (int)sm;
+        for (int s = 32; s >= 1; s >>= 1) { m10 += __shfl_xor(m10, s, 64); m01 += __shfl_xor(m01, s, 64); }
+    };
+    static_assert(kKpPerWave == 4, "the schedule below is written out for four keypoints");
+    u32x4 disc[kKpPerWave];
+    Window fa, fb;
+#pragma unroll
+    for (int q = 0; q < kKpPerWave; ++q) fetch_disc(q, disc[q]);
+    fetch_window(0, fa);
+    fetch_window(1, fb);
+    int my10 = 0, my01 = 0;
+#pragma unroll
+    for (int q = 0; q < kKpPerWave; ++q) {
+        int m10, m01;
+        moments(disc[q], m10, m01);
+        if (lane == q) { my10 = m10; my01 = m01; }
+    }
+    const float my_angle = fast_atan2_deg((float)my01, (float)my10);
+    // computeOrbDescriptor (src/ORBextractor.cc:107-146)
+    constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.0); // (float)(CV_PI/180.f)
+    double sd, cd;
+    sincos_0_2pi((double)__fmul_rn(my_angle, factorPI), sd, cd);
+    const float my_a = (float)cd, my_b = (float)sd;
+
+    auto stage = [&](int q, const Window& f) __attribute__((always_inline)) {      // window registers -> LDS
         if (jlevel[q] < 0) return;
-        const int level = jlevel[q];
-        const DevLevel& L = lv[level];
-        const int kx = (int)(jkey[q] >> 20) + kMinBorder, ky = (int)((jkey[q] >> 8) & 0xFFF) + kMinBorder;
-        const int resp = (int)(jkey[q] & 0xFF);
         wave_sync();        // the previous keypoint's tests have read the window
         u32x4* winv = reinterpret_cast<u32x4*>(win);
         winv[lane] = f.w0;
         winv[lane + 64] = f.w1;
         if (lane + 128 < kBlurW * kWinChunks) winv[lane + 128] = f.w2;
+    };
+    auto process = [&](int q) __attribute__((always_inline)) {
+        if (jlevel[q] < 0) return;
+        const int level = jlevel[q];
+        const DevLevel& L = lv[level];
+        int kx, ky; key_xy(q, kx, ky);
+        const int resp = (int)(jkey[q] & 0xFF);
+        const float angle = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_angle), q));
+        const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_a), q));
+        const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_b), q));
         const int wshift = (kx - 18) & 15;
-
-        // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc, four pixels per
-        // v_dot4_u32_u8.  m10 = sum u*I = sum (u+16)*I - 16*sum I,  m01 = sum v*I; bytes outside the disc have weight 0.
-        int m10 = 0, m01 = 0;
-        if (disc_lane) {
-            const uint32_t px[4] = {f.d[0], f.d[1], f.d[2], f.d[3]};
-            uint32_t su = 0, sm = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                su = __builtin_amdgcn_udot4(px[k], cwu[k], su, false);
-                sm = __builtin_amdgcn_udot4(px[k], cwm[k], sm, false);
-            }
-            m10 = (int)su - 16 * (int)sm;
-            m01 = cv * (int)sm;
-        }
-        for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
-        const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-        // computeOrbDescriptor (src/ORBextractor.cc:107-146)
-        constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.0); // (float)(CV_PI/180.f)
-        const float ang = __fmul_rn(angle, factorPI);
-        double sd, cd;
-        sincos_0_2pi((double)ang, sd, cd);
-        const float a = (float)cd, b = (float)sd;
         const size_t orow = (size_t)frame * cap_per_frame + jout[q];
         unsigned long long* dout = reinterpret_cast<unsigned long long*>(odesc + orow * 32);
         wave_sync();
@@ -1068,13 +1091,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             okp[orow] = kp;
         }
     };
-    static_assert(kKpPerWave == 4, "the schedule below is written out for four keypoints");
-    Fetched fa, fb;
-    fetch(0, fa);
-    fetch(1, fb); process(0, fa);
-    fetch(2, fa); process(1, fb);
-    fetch(3, fb); process(2, fa);
-    process(3, fb);
+    stage(0, fa); fetch_window(2, fa); process(0);
+    stage(1, fb); fetch_window(3, fb); process(1);
+    stage(2, fa); process(2);
+    stage(3, fb); process(3);
 }
 
 // ---------------------------------------------------------------------------------------------
