@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--contexts", type=int, default=4,
+    ap.add_argument("--contexts", type=int, default=8,
                     help="extractor contexts per GPU, each on its own HIP stream with batch/contexts frames "
                          "(the reference runs two extractors concurrently for stereo, src/Frame.cc:78-81)")
     ap.add_argument("--width", type=int, default=640)
