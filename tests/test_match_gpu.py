@@ -176,7 +176,7 @@ def test_stereo_match(vsa, oracle, matcher, stereo_features):
 
 
 def test_stereo_pipeline_device_resident(vsa, oracle, matcher):
-    """BASELINE config 2 shape: left+right extraction then stereo Hamming, all buffers in HBM."""
+    """The 752x480 stereo shape: left+right extraction then stereo Hamming, all buffers in HBM."""
     torch = pytest.importorskip("torch")
     w, h, B = 752, 480, 2
     p = vsa.make_params()

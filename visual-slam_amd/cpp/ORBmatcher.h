@@ -2,7 +2,7 @@
 // Frame / KeyFrame / MapPoint belong to the reference's map data model and are not rebuilt here; the
 // Search* methods take a FrameView (the fields of Frame the reference reads) and plain query arrays.
 // A maintainer of the reference keeps the original signatures and forwards to these from the places cited
-// on each method (see INTEGRATION.md).
+// on each method.
 #ifndef ORBX_ORBMATCHER_H
 #define ORBX_ORBMATCHER_H
 
