@@ -166,14 +166,15 @@ int orbx_vocabulary_create(int device, int k, int L, int scoring, int weighting,
         std::memcpy(&slot_desc[(size_t)s * 32], descriptors + (size_t)i * 32, 32);
     }
     orbx_vocabulary* v = new orbx_vocabulary();
+    struct Guard { orbx_vocabulary* p; ~Guard() { orbx_vocabulary_destroy(p); } } guard{v};
     for (int i = 1; i < n_nodes; ++i) {
         const bool leaf = is_leaf[i] != 0, childless = first[(size_t)i + 1] == first[i];
-        if (leaf != childless) { delete v; set_error("vocabulary: leaf flag disagrees with the children lists"); return ORBX_ERR_BAD_ARG; }
+        if (leaf != childless) { set_error("vocabulary: leaf flag disagrees with the children lists"); return ORBX_ERR_BAD_ARG; }
         if (leaf) { word_of[i] = v->n_words++; v->word_weight.push_back(weight[i]); }
     }
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { delete v; set_error("no HIP device visible"); return ORBX_ERR_NO_DEVICE; }
-    if (device >= count) { delete v; set_error("device index out of range"); return ORBX_ERR_BAD_ARG; }
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return ORBX_ERR_NO_DEVICE; }
+    if (device >= count) { set_error("device index out of range"); return ORBX_ERR_BAD_ARG; }
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipGetDevice(&v->device));
     v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting; v->n_nodes = n_nodes;
@@ -186,6 +187,7 @@ int orbx_vocabulary_create(int device, int k, int L, int scoring, int weighting,
     HIP_CHECK(hipMemcpy(v->d_slot_desc, slot_desc.data(), slot_desc.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(v->d_slot_node, slot_node.data(), sizeof(int32_t) * slot_node.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(v->d_word_of, word_of.data(), sizeof(int32_t) * word_of.size(), hipMemcpyHostToDevice));
+    guard.p = nullptr;
     *out = v;
     return ORBX_OK;
 }

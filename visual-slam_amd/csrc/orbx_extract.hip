@@ -1353,6 +1353,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     rc = select_device(device);
     if (rc) return rc;
     orbx_extractor* ex = new orbx_extractor();
+    struct Guard { orbx_extractor* e; ~Guard() { orbx_extractor_destroy(e); } } guard{ex};    // a failed step releases what was allocated
     ex->params = *p; ex->geo = geo; ex->max_batch = max_batch;
     HIP_CHECK(hipGetDevice(&ex->device));
     ex->hlv.resize(geo.nlevels);
@@ -1437,6 +1438,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK(hipMalloc(&ex->d_lvlcnt, sizeof(int32_t) * geo.nlevels * B));
     for (auto& e : ex->ev) HIP_CHECK(hipEventCreate(&e));
     ex->no_graph = getenv("ORBX_NO_GRAPH") != nullptr;
+    guard.e = nullptr;
     *out = ex;
     return ORBX_OK;
 }

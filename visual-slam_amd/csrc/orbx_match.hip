@@ -375,8 +375,10 @@ int orbx_matcher_create(int device, orbx_matcher** out)
     if (device >= count) { set_error("device index out of range"); return ORBX_ERR_BAD_ARG; }
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
     orbx_matcher* m = new orbx_matcher();
+    struct Guard { orbx_matcher* p; ~Guard() { orbx_matcher_destroy(p); } } guard{m};
     HIP_CHECK(hipGetDevice(&m->device));
     HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    guard.p = nullptr;
     *out = m;
     return ORBX_OK;
 }

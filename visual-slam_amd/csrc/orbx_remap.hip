@@ -187,19 +187,21 @@ int orbx_remap_create(int device, const float* map_x, const float* map_y, ptrdif
     if (device >= count) { set_error("device index out of range"); return ORBX_ERR_BAD_ARG; }
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
     orbx_remapper* r = new orbx_remapper();
+    struct Guard { orbx_remapper* p; ~Guard() { orbx_remap_destroy(p); } } guard{r};
     HIP_CHECK(hipGetDevice(&r->device));
     r->sw = src_w; r->sh = src_h; r->dw = dst_w; r->dh = dst_h;
     HIP_CHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
     const size_t n = (size_t)dst_w * dst_h;
-    float *d_mx = nullptr, *d_my = nullptr;
-    HIP_CHECK(hipMalloc(&d_mx, sizeof(float) * n)); HIP_CHECK(hipMalloc(&d_my, sizeof(float) * n));
+    struct Maps { float *x = nullptr, *y = nullptr; ~Maps() { if (x) (void)hipFree(x); if (y) (void)hipFree(y); } } maps;
+    HIP_CHECK(hipMalloc(&maps.x, sizeof(float) * n)); HIP_CHECK(hipMalloc(&maps.y, sizeof(float) * n));
+    float *d_mx = maps.x, *d_my = maps.y;
     HIP_CHECK(hipMalloc(&r->d_xy, sizeof(uint32_t) * n)); HIP_CHECK(hipMalloc(&r->d_frac, sizeof(uint16_t) * n));
     HIP_CHECK(hipMemcpy2D(d_mx, sizeof(float) * dst_w, map_x, sizeof(float) * map_stride, sizeof(float) * dst_w, dst_h, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy2D(d_my, sizeof(float) * dst_w, map_y, sizeof(float) * map_stride, sizeof(float) * dst_w, dst_h, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_remap_prepare, dim3((dst_w + 255) / 256, dst_h), dim3(256), 0, r->stream, d_mx, d_my, (long long)dst_w, dst_w, dst_h, r->d_xy, r->d_frac);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(r->stream));
-    (void)hipFree(d_mx); (void)hipFree(d_my);
+    guard.p = nullptr;
     *out = r;
     return ORBX_OK;
 }
