@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Large parity sweep: N synthetic frames through the GPU extractor (batched) and through the CPU oracle (one extractor per
+host thread), every keypoint field and descriptor byte compared.  usage: parity_sweep.py [frames] [width height nfeatures]"""
+import concurrent.futures as cf
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+vsa = importlib.import_module("visual-slam_amd")
+import oracle_lib as orc
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+w, h, nf = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (640, 480, 1000)
+B = 250
+ex = vsa.Extractor(vsa.make_params(nf), w, h, max_batch=B, device=0)
+threads = 16
+bad = kp_total = 0
+t0 = time.time()
+for b0 in range(0, n, B):
+    m = min(B, n - b0)
+    imgs = np.stack([vsa.synth_frame(10_000 + b0 + i, w, h) for i in range(m)])
+    kps, desc, counts = ex.extract_batch(imgs)
+
+    def check(part):
+        oex = orc.Extractor(orc.make_params(nf))
+        wrong = []
+        for i in part:
+            ok, od = oex.extract(imgs[i])
+            c = counts[i]
+            if c != len(ok) or not np.array_equal(desc[i, :c], od) or not np.array_equal(kps[i, :c], ok.astype(vsa.KEYPOINT_DTYPE)):
+                wrong.append(b0 + i)
+        return wrong
+    with cf.ThreadPoolExecutor(threads) as pool:
+        for wrong in pool.map(check, [range(t, m, threads) for t in range(threads)]):
+            bad += len(wrong)
+            for f in wrong:
+                print("MISMATCH frame", f)
+    kp_total += int(counts.sum())
+    print(f"{b0 + m} frames, {kp_total} keypoints, {bad} mismatching frames, {time.time() - t0:.0f} s", flush=True)
+print("sweep done:", n, "frames", kp_total, "keypoints", bad, "mismatching frames")
+sys.exit(1 if bad else 0)
