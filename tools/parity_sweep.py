@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Large parity sweep: N synthetic frames through the GPU extractor (batched) and through the CPU oracle (one extractor per
-host thread), every keypoint field and descriptor byte compared.  usage: parity_sweep.py [frames] [width height nfeatures]"""
+host thread), every keypoint field and descriptor byte compared.  usage: parity_sweep.py [frames] [width height nfeatures] [mode]   mode: plain | lowcontrast | noise | smooth"""
 import concurrent.futures as cf
 import importlib, os, sys, time
 import numpy as np
@@ -11,14 +11,30 @@ import oracle_lib as orc
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 w, h, nf = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (640, 480, 1000)
+mode = sys.argv[5] if len(sys.argv) > 5 else "plain"
 B = 250
+
+
+def frame(i):
+    f = vsa.synth_frame(10_000 + i, w, h)
+    if mode == "lowcontrast":          # most cells fall back to the lower threshold
+        return ((f.astype(np.int32) - 128) // 5 + 128).astype(np.uint8)
+    if mode == "noise":                # corners everywhere: the quadtree sees tens of thousands of candidates
+        rng = np.random.default_rng(i)
+        return np.clip(f.astype(np.int32) + rng.integers(-40, 41, f.shape), 0, 255).astype(np.uint8)
+    if mode == "smooth":               # box-blurred: few, weak corners
+        g = f.astype(np.uint16)
+        g = (g + np.roll(g, 1, 0) + np.roll(g, -1, 0) + np.roll(g, 1, 1) + np.roll(g, -1, 1) + 2) // 5
+        return g.astype(np.uint8)
+    return f
+
 ex = vsa.Extractor(vsa.make_params(nf), w, h, max_batch=B, device=0)
 threads = 16
 bad = kp_total = 0
 t0 = time.time()
 for b0 in range(0, n, B):
     m = min(B, n - b0)
-    imgs = np.stack([vsa.synth_frame(10_000 + b0 + i, w, h) for i in range(m)])
+    imgs = np.stack([frame(b0 + i) for i in range(m)])
     kps, desc, counts = ex.extract_batch(imgs)
 
     def check(part):
