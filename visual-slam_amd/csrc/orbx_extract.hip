@@ -758,6 +758,10 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
         const bool even_ties = MODE != 0 && x < (L.w & ~3);
         uint32_t* out = reinterpret_cast<uint32_t*>(stage + ((lane >> 2) * kBlurUnitBytes + 4 * (lane & 3)));   // + 16 bytes per row
         constexpr uint32_t T0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), T1 = 49u | (34u << 8) | (18u << 16);
+        // horizontal taps 18 34 49 55 49 34 18 centred on pixel x+k, cut into the words that meet t.a / t.b / t.c
+        constexpr uint32_t A0 = (18u << 8) | (34u << 16) | (49u << 24), B0 = 55u | (49u << 8) | (34u << 16) | (18u << 24);
+        constexpr uint32_t A1 = (18u << 16) | (34u << 24), B1 = 49u | (55u << 8) | (49u << 16) | (34u << 24), C1 = 18u;
+        constexpr uint32_t A2 = 18u << 24, B2 = 34u | (49u << 8) | (55u << 16) | (49u << 24), C2 = 34u | (18u << 8);
         constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
         constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
         uint32_t P[4][4];               // last four row pairs: per pixel, sums of rows 2j | 2j+1 << 16
@@ -767,12 +771,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const u96 t = *reinterpret_cast<const u96*>(src + (vo + (uint32_t)(2 * j + r) * stride));
-                h[r][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 1), T1,
-                              __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 1), T0, 0u, false), false);
-                h[r][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 2), T1,
-                              __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 2), T0, 0u, false), false);
-                h[r][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.c, t.b, 3), T1,
-                              __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t.b, t.a, 3), T0, 0u, false), false);
+                // t.a = pixels x-4..x-1, t.b = x..x+3, t.c = x+4..x+7: instead of shifting the pixels under one pair of
+                // tap words, each output uses the tap words shifted to its position (10 dot products per row, no byte align)
+                h[r][0] = __builtin_amdgcn_udot4(t.b, B0, __builtin_amdgcn_udot4(t.a, A0, 0u, false), false);
+                h[r][1] = __builtin_amdgcn_udot4(t.c, C1, __builtin_amdgcn_udot4(t.b, B1, __builtin_amdgcn_udot4(t.a, A1, 0u, false), false), false);
+                h[r][2] = __builtin_amdgcn_udot4(t.c, C2, __builtin_amdgcn_udot4(t.b, B2, __builtin_amdgcn_udot4(t.a, A2, 0u, false), false), false);
                 h[r][3] = __builtin_amdgcn_udot4(t.c, T1, __builtin_amdgcn_udot4(t.b, T0, 0u, false), false);
             }
 #pragma unroll
