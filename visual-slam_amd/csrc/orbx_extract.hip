@@ -787,11 +787,16 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
                 for (int k = 0; k < 4; ++k) {
 #define ORBX_DOT2(a, w, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, (uint32_t)(a)), __builtin_bit_cast(us16x2, (uint32_t)(w)), acc, false)
                     const uint32_t d0 = P[m & 3][k], d1 = P[(m + 1) & 3][k], d2 = P[(m + 2) & 3][k], d3 = P[(m + 3) & 3][k];
-                    const uint32_t se = ORBX_DOT2(d3, E3, ORBX_DOT2(d2, E2, ORBX_DOT2(d1, E1, ORBX_DOT2(d0, E0, 0u))));
-                    const uint32_t so = ORBX_DOT2(d3, O3, ORBX_DOT2(d2, O2, ORBX_DOT2(d1, O1, ORBX_DOT2(d0, O0, 0u))));
+                    // the rounding constant of (sum + 32768) >> 16 rides in as the accumulator's start value
+                    constexpr uint32_t kStart = MODE == 0 ? 32768u : 0u;
+                    const uint32_t se = ORBX_DOT2(d3, E3, ORBX_DOT2(d2, E2, ORBX_DOT2(d1, E1, ORBX_DOT2(d0, E0, kStart))));
+                    const uint32_t so = ORBX_DOT2(d3, O3, ORBX_DOT2(d2, O2, ORBX_DOT2(d1, O1, ORBX_DOT2(d0, O0, kStart))));
 #undef ORBX_DOT2
-                    te[k] = se + (even_ties ? 32767u + ((se >> 16) & 1u) : 32768u);
-                    to[k] = so + (even_ties ? 32767u + ((so >> 16) & 1u) : 32768u);
+                    if (MODE == 0) { te[k] = se; to[k] = so; }
+                    else {
+                        te[k] = se + (even_ties ? 32767u + ((se >> 16) & 1u) : 32768u);
+                        to[k] = so + (even_ties ? 32767u + ((so >> 16) & 1u) : 32768u);
+                    }
                 }
                 // bits 16..24 of each sum hold the rounded value (at most 257): gather as 16-bit pairs, clamp, pack bytes
                 const us16x2 lim = {255, 255};
