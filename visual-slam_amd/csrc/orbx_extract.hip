@@ -1013,9 +1013,12 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             const uint32_t y = (uint32_t)(ky - 18) + r;
             return __umul24(y >> 3, tile_row_bytes) + 16u * (y & 7u) + 8u * col16;   // col16 = 16 * column index
         };
-        f.w0 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[0], wcol[0]));
-        f.w1 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[1], wcol[1]));
-        if (lane + 128 < kBlurW * kWinChunks) f.w2 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[2], wcol[2]));
+        // the 37 columns start at byte (kx-18) & 15 of the first chunk: the fourth chunk of a row is only touched when
+        // that offset is 12 or more (a quarter of the keypoints)
+        const uint32_t last = ((uint32_t)(kx - 18) & 15u) >= 12u ? 64u : 48u;
+        if (wcol[0] < last) f.w0 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[0], wcol[0]));
+        if (wcol[1] < last) f.w1 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[1], wcol[1]));
+        if (lane + 128 < kBlurW * kWinChunks && wcol[2] < last) f.w2 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[2], wcol[2]));
     };
     // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc, four pixels per
     // v_dot4_u32_u8.  m10 = sum u*I = sum (u+16)*I - 16*sum I,  m01 = sum v*I; bytes outside the disc have weight 0.
