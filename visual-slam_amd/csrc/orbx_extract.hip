@@ -41,7 +41,7 @@ struct DevLevel {
     int quota, nIni;
     float hX;
     int kp_offset, kp_cap;
-    int area2x, rx_offset, ry_offset;
+    int area2x, rx_offset, ry_offset, rb_offset;
     float scale, kp_size;
     int key_offset;   // offset of this level's compact key array inside one frame's key scratch
     int fast_resize;  // every aligned group of 4 destination columns reads <= 8 consecutive source bytes
@@ -206,13 +206,28 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img,
 // Level l from level l-1: cv::resize INTER_LINEAR for 8-bit (Q11 weights, two-stage rounding).
 // A thread owns one group of four adjacent destination columns over four consecutive rows, and consecutive
 // lanes own consecutive groups, so each load or store of a wavefront touches a few cache lines.  The four
-// columns read at most 8 consecutive source bytes per row; one v_perm_b32 pulls a column's two neighbours out
-// of that window as 16-bit lanes, one v_dot2_u32_u16 applies the weights.  Frame columns are ordinary groups
-// (their table entries repeat the mirror column); frame rows are second stores of the rows they mirror.
+// columns read at most 8 consecutive source bytes per row: they arrive as one 4-byte-aligned 12-byte load
+// (an unaligned 8-byte load costs the address unit about twice as much) shifted into place by two
+// v_alignbyte_b32; one v_perm_b32 pulls a column's two neighbours out of that window as 16-bit lanes, one
+// v_dot2_u32_u16 applies the weights.  All loads of a thread are issued before the first store.
+// kSharedRows: the four destination rows read source rows base+r or base+r+1 (and the row below), which holds
+// for every scale factor up to 4/3; then six source rows are loaded instead of eight and the row constants come
+// as one 16-byte record per row block.  Otherwise each destination row loads its own two rows.
+// Frame columns are ordinary groups (their table entries repeat the mirror column); frame rows are second
+// stores of the rows they mirror.
 constexpr int kResizeRows = 4;
+struct __attribute__((packed, aligned(4))) u96_aligned4 { uint32_t x, y, z; };
+
+__device__ __forceinline__ uint2 resize_window(const uint8_t* p, uint32_t shift)     // 8 bytes at p + shift, p 4-byte aligned
+{
+    const u96_aligned4 t = *reinterpret_cast<const u96_aligned4*>(p);
+    return make_uint2(__builtin_amdgcn_alignbyte(t.y, t.x, shift), __builtin_amdgcn_alignbyte(t.z, t.y, shift));
+}
+
+template <bool kSharedRows>
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel S, DevLevel D,
-                                                const ResizeY* __restrict__ ryt, const ResizeGroupA* __restrict__ rga,
-                                                const ResizeGroupB* __restrict__ rgb, int n_frames)
+                                                const ResizeY* __restrict__ ryt, const ResizeRowBlock* __restrict__ rrb,
+                                                const ResizeGroupA* __restrict__ rga, const ResizeGroupB* __restrict__ rgb, int n_frames)
 {
     const uint32_t nthreads = (uint32_t)(D.gpr * ((D.h + kResizeRows - 1) / kResizeRows));
     int frame; uint32_t blk;
@@ -232,25 +247,58 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
         sel[k] = (off | (off << 16)) + 0x0c010c00u;                             // bytes off, off+1 -> 16-bit lanes 0, 1
     }
     // all products below fit 24-bit operands: rows < 2^15, strides < 2^13, weights <= 2048, sums >> 4 < 2^15
-    const uint8_t* scol = base + S.roi + (int)ta.x;
+    const uint32_t shift = (uint32_t)(int)ta.x & 3u;                            // level origins and strides are multiples of 32
+    const uint8_t* scol = base + S.roi + ((int)ta.x - (int)shift);
     uint8_t* dcol = base + D.roi + 4 * ((int)gx - 1);
+    const int y0 = (int)rb * kResizeRows;
+    uint2 r0[kResizeRows], r1[kResizeRows];
+    uint32_t b0[kResizeRows], b1[kResizeRows];
+    if constexpr (kSharedRows) {
+        const uint4 tr = *reinterpret_cast<const uint4*>(rrb + D.rb_offset + rb);
+        const uint32_t rec[4] = {tr.x, tr.y, tr.z, tr.w};
+        const int sbase = (int)((tr.x >> 25) | ((tr.y >> 25) << 7) | ((tr.z >> 25) << 14));
+        uint2 rows[kResizeRows + 2];
+#pragma unroll
+        for (int k = 0; k < kResizeRows + 2; ++k)
+            rows[k] = resize_window(scol + __umul24((uint32_t)min(sbase + k, S.h - 1), (uint32_t)S.stride), shift);
+#pragma unroll
+        for (int r = 0; r < kResizeRows; ++r) {
+            const bool up = rec[r] & (1u << 24);
+            r0[r] = up ? rows[r + 1] : rows[r];
+            r1[r] = up ? rows[r + 2] : rows[r + 1];
+            b0[r] = rec[r] & 0xFFFu; b1[r] = (rec[r] >> 12) & 0xFFFu;
+        }
+    } else {
+        // rows past the bottom edge repeat the last row and are not stored
+        ResizeY ey[kResizeRows];
+#pragma unroll
+        for (int r = 0; r < kResizeRows; ++r) ey[r] = ryt[D.ry_offset + min(y0 + r, D.h - 1)];
+#pragma unroll
+        for (int r = 0; r < kResizeRows; ++r) {
+            r0[r] = resize_window(scol + __umul24((uint32_t)ey[r].sy0, (uint32_t)S.stride), shift);
+            r1[r] = resize_window(scol + __umul24((uint32_t)ey[r].sy1, (uint32_t)S.stride), shift);
+            b0[r] = (uint32_t)(int)ey[r].b0; b1[r] = (uint32_t)(int)ey[r].b1;
+        }
+    }
+    uint32_t out[kResizeRows];
 #pragma unroll
     for (int r = 0; r < kResizeRows; ++r) {
-        const int y = (int)rb * kResizeRows + r;
-        if (y >= D.h) break;
-        const ResizeY ey = ryt[D.ry_offset + y];
-        const u64_unaligned r0 = *reinterpret_cast<const u64_unaligned*>(scol + __umul24((uint32_t)ey.sy0, (uint32_t)S.stride));
-        const u64_unaligned r1 = *reinterpret_cast<const u64_unaligned*>(scol + __umul24((uint32_t)ey.sy1, (uint32_t)S.stride));
-        const uint32_t b0 = (uint32_t)(int)ey.b0, b1 = (uint32_t)(int)ey.b1;
         uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const us16x2 w = __builtin_bit_cast(us16x2, wt[k]);
-            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r0.y, r0.x, sel[k])), w, 0u, false);
-            const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r1.y, r1.x, sel[k])), w, 0u, false);
-            const uint32_t b = (((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2) & 0xFFu;
+            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r0[r].y, r0[r].x, sel[k])), w, 0u, false);
+            const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r1[r].y, r1[r].x, sel[k])), w, 0u, false);
+            const uint32_t b = (((__umul24(b0[r], h0 >> 4) >> 16) + (__umul24(b1[r], h1 >> 4) >> 16) + 2u) >> 2) & 0xFFu;
             v |= b << (8 * k);
         }
+        out[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < kResizeRows; ++r) {
+        const int y = y0 + r;
+        if (y >= D.h) break;
+        const uint32_t v = out[r];
         *reinterpret_cast<uint32_t*>(dcol + __umul24((uint32_t)y, (uint32_t)D.stride)) = v;
         // frame row -j repeats row j, row h-1+j repeats row h-1-j (j = 1..kFrameFill)
         const bool top = (uint32_t)(y - 1) < (uint32_t)kFrameFill, bottom = (uint32_t)(D.h - 2 - y) < (uint32_t)kFrameFill;
@@ -1283,6 +1331,7 @@ struct orbx_extractor {
     int n_small = 0, n_big = 0;
     ResizeX* d_rx = nullptr;
     ResizeY* d_ry = nullptr;
+    ResizeRowBlock* d_rrb = nullptr;
     ResizeGroupA* d_rga = nullptr;
     ResizeGroupB* d_rgb = nullptr;
     uint8_t* d_pyr = nullptr;
@@ -1376,7 +1425,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         d.maxBorderX = g.maxBorderX; d.maxBorderY = g.maxBorderY;
         d.cell_first = g.cell_first; d.cell_count = g.cell_count; d.cand_offset = g.cand_offset; d.cand_cap = g.cand_cap;
         d.quota = g.quota; d.nIni = g.nIni; d.hX = g.hX; d.kp_offset = g.kp_offset; d.kp_cap = g.kp_cap;
-        d.area2x = g.area2x; d.rx_offset = g.rx_offset; d.ry_offset = g.ry_offset; d.scale = g.scale; d.inv_scale = geo.tables.inv_scale[l]; d.kp_size = g.kp_size;
+        d.area2x = g.area2x; d.rx_offset = g.rx_offset; d.ry_offset = g.ry_offset; d.rb_offset = g.rb_offset; d.scale = g.scale; d.inv_scale = geo.tables.inv_scale[l]; d.kp_size = g.kp_size;
         d.key_offset = key_off;
         d.fast_resize = g.fast_resize;
         if (l > 0 && !g.fast_resize) ++ex->generic_levels;
@@ -1420,6 +1469,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK(hipMalloc(&ex->d_cells, sizeof(CellRec) * std::max<size_t>(geo.cells.size(), 1)));
     HIP_CHECK(hipMalloc(&ex->d_rx, sizeof(ResizeX) * std::max<size_t>(geo.rx.size(), 1)));
     HIP_CHECK(hipMalloc(&ex->d_ry, sizeof(ResizeY) * std::max<size_t>(geo.ry.size(), 1)));
+    HIP_CHECK(hipMalloc(&ex->d_rrb, sizeof(ResizeRowBlock) * std::max<size_t>(geo.rrb.size(), 1)));
     HIP_CHECK(hipMemcpy(ex->d_lv, ex->hlv.data(), sizeof(DevLevel) * geo.nlevels, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(ex->d_cells, geo.cells.data(), sizeof(CellRec) * geo.cells.size(), hipMemcpyHostToDevice));
     {
@@ -1433,6 +1483,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     }
     if (!geo.rx.empty()) HIP_CHECK(hipMemcpy(ex->d_rx, geo.rx.data(), sizeof(ResizeX) * geo.rx.size(), hipMemcpyHostToDevice));
     if (!geo.ry.empty()) HIP_CHECK(hipMemcpy(ex->d_ry, geo.ry.data(), sizeof(ResizeY) * geo.ry.size(), hipMemcpyHostToDevice));
+    if (!geo.rrb.empty()) HIP_CHECK(hipMemcpy(ex->d_rrb, geo.rrb.data(), sizeof(ResizeRowBlock) * geo.rrb.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&ex->d_rga, sizeof(ResizeGroupA) * std::max<size_t>(geo.rga.size(), 1)));
     HIP_CHECK(hipMalloc(&ex->d_rgb, sizeof(ResizeGroupB) * std::max<size_t>(geo.rgb.size(), 1)));
     if (!geo.rga.empty()) HIP_CHECK(hipMemcpy(ex->d_rga, geo.rga.data(), sizeof(ResizeGroupA) * geo.rga.size(), hipMemcpyHostToDevice));
@@ -1459,7 +1510,7 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    void* ptrs[] = {ex->d_pts, ex->d_octmem, ex->d_lv, ex->d_cells, ex->d_cell_list, ex->d_rx, ex->d_ry, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
+    void* ptrs[] = {ex->d_pts, ex->d_octmem, ex->d_lv, ex->d_cells, ex->d_cell_list, ex->d_rx, ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
                     ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     void* hptrs[] = {ex->h_pts, ex->h_img, ex->h_okp, ex->h_odesc, ex->h_ocount, ex->h_level};
@@ -1505,8 +1556,12 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
             const DevLevel& D = ex->hlv[l];
             if (D.fast_resize) {
                 dim3 g2(frame_chunk_grid((D.gpr * ((D.h + kResizeRows - 1) / kResizeRows) + 255) / 256, B));
-                hipLaunchKernelGGL(k_resize, g2, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
-                                   ex->d_ry, ex->d_rga, ex->d_rgb, B);
+                if (D.fast_resize == 2)
+                    hipLaunchKernelGGL(k_resize<true>, g2, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
+                                       ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, B);
+                else
+                    hipLaunchKernelGGL(k_resize<false>, g2, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
+                                       ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, B);
             } else {
                 dim3 g2((D.w + 255) / 256, (D.h + 3) / 4, B);
                 hipLaunchKernelGGL(k_resize_generic, g2, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,

@@ -106,7 +106,7 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
     if (rc) return rc;
     g.width = width; g.height = height; g.nlevels = p.nlevels;
     g.lv.assign(p.nlevels, LevelGeom());
-    g.cells.clear(); g.rx.clear(); g.ry.clear(); g.rga.clear(); g.rgb.clear();
+    g.cells.clear(); g.rx.clear(); g.ry.clear(); g.rrb.clear(); g.rga.clear(); g.rgb.clear();
     size_t off = 0, boff = 0;
     int cand_off = 0, kp_off = 0;
     g.out_cap = 0; g.max_cell_dim = 0;
@@ -201,7 +201,7 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
         g.out_cap += L.kp_cap;
 
         L.area2x = 0; L.fast_resize = 0; L.rx_offset = (int)g.rx.size(); L.ry_offset = (int)g.ry.size();
-        L.rg_offset = (int)g.rga.size();
+        L.rg_offset = (int)g.rga.size(); L.rb_offset = (int)g.rrb.size();
         if (l > 0) {
             build_resize_tables(g.lv[l - 1].w, g.lv[l - 1].h, L.w, L.h, g.rx, g.ry, L.area2x);
             // fast kernel: every aligned group of four destination columns must read <= 8 consecutive source bytes
@@ -232,6 +232,25 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
                 g.rga.push_back(ra); g.rgb.push_back(rb);
             }
             if (!L.fast_resize) { g.rga.resize(mark); g.rgb.resize(mark); }
+            // row blocks: four destination rows that step through the source one or two rows at a time
+            const int sh = g.lv[l - 1].h;
+            const size_t rmark = g.rrb.size();
+            for (int y0 = 0; y0 < L.h && L.fast_resize; y0 += 4) {
+                const int sbase = g.ry[L.ry_offset + y0].sy0;
+                ResizeRowBlock rec{};
+                bool fits = sbase < (1 << 21);
+                for (int r = 0; r < 4 && fits; ++r) {
+                    if (y0 + r >= L.h) break;                       // rows below the image are computed but not stored
+                    const ResizeY& e = g.ry[L.ry_offset + y0 + r];
+                    const int d = e.sy0 - sbase;
+                    fits = (d == r || d == r + 1) && e.sy1 == std::min(e.sy0 + 1, sh - 1) && e.b0 >= 0 && e.b0 < 4096 && e.b1 >= 0 && e.b1 < 4096;
+                    rec.w[r] = (uint32_t)e.b0 | ((uint32_t)e.b1 << 12) | ((d == r + 1 ? 1u : 0u) << 24);
+                }
+                if (!fits) { g.rrb.resize(rmark); break; }
+                for (int k = 0; k < 3; ++k) rec.w[k] |= (((uint32_t)sbase >> (7 * k)) & 0x7Fu) << 25;
+                g.rrb.push_back(rec);
+                if (y0 + 4 >= L.h) L.fast_resize = 2;
+            }
         }
     }
     g.pyr_bytes = off;

@@ -46,6 +46,9 @@ struct ResizeX { int32_t sx; int16_t a0, a1; };          // source column and Q1
 struct ResizeGroupA { int32_t sx_first; uint32_t offs; uint32_t w01[2]; };
 struct ResizeGroupB { uint32_t w23[2]; };
 struct ResizeY { int16_t sy0, sy1; int16_t b0, b1; };    // clamped source rows and Q11 weights of one destination row
+// Four consecutive destination rows whose source rows are base+r or base+r+1 (and the row below, clamped at the last row):
+// w[r] = b0 | b1 << 12 | (sy0 == base+r+1) << 24; bits 25..31 of w[0], w[1], w[2] hold base (7 bits each, low first)
+struct ResizeRowBlock { uint32_t w[4]; };
 
 struct LevelGeom {
     int w, h;               // ROI size (src/ORBextractor.cc:1111)
@@ -60,7 +63,8 @@ struct LevelGeom {
     int kp_offset, kp_cap;  // selected-keypoint slots of this level inside one frame's per-level array
     int area2x;             // resize from the previous level is an exact 2x2 decimation (OpenCV reroutes to INTER_AREA)
     int rx_offset, ry_offset; // offsets into the ResizeX / ResizeY tables (rx_offset is a multiple of 4)
-    int fast_resize;        // every aligned group of 4 destination columns reads <= 8 consecutive source bytes
+    int rb_offset;            // first ResizeRowBlock of this level (fast_resize == 2)
+    int fast_resize;        // 1: every aligned group of 4 destination columns reads <= 8 consecutive source bytes; 2: and every block of 4 rows fits ResizeRowBlock
     int rg_offset;          // first group record of this level
     int gpr;                // groups per row that the resize kernel writes: 1 + ceil((w + kFrameFill) / 4)
     unsigned gpr_magic;     // ceil(2^32 / gpr)
@@ -81,6 +85,7 @@ struct Geometry {
     std::vector<CellRec> cells;
     std::vector<ResizeX> rx;
     std::vector<ResizeY> ry;
+    std::vector<ResizeRowBlock> rrb;
     std::vector<ResizeGroupA> rga;
     std::vector<ResizeGroupB> rgb;
     size_t pyr_bytes = 0;     // one frame's pyramid block
