@@ -994,9 +994,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
 
     // lane constants.  Window: 16-byte chunk l = lane, lane + 64 of the 37 x 3 chunks -> (row, byte).  Disc: lane
     // 2*row + half reads 16 bytes of disc row `row` from column -16 + 16*half, with the weights of its four dwords.
-    uint32_t wrow[3], wcol[3];
+    uint32_t wcol[3], wrem[3];          // chunk column and row offset from the first tile row of window slot lane + 64 k
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const uint32_t l = min(lane + 64 * k, kBlurW * kWinChunks - 1); wrow[k] = l / kWinChunks; wcol[k] = 16 * (l - wrow[k] * kWinChunks); }
+    for (int k = 0; k < 3; ++k) { const uint32_t sl = lane + 64 * k; wcol[k] = sl / 48u; wrem[k] = sl - 48u * wcol[k]; }
     const bool disc_lane = lane < 2 * kPatch;
     const int crow = min(lane >> 1, kPatch - 1), chalf = lane & 1;
     const int cv = crow - kHalfPatch;
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     // orientations are then computed together, keypoint q in lane q (one pass through fastAtan2 and the double-precision
     // sin / cos instead of four); each keypoint's 256 tests run with the window loads of the keypoint two ahead in flight.
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    struct Window { u32x4 w0, w1, w2; };
+    struct Window { u32x4 w[3]; };
     auto key_xy = [&](int q, int& kx, int& ky) __attribute__((always_inline)) {
         kx = (int)(jkey[q] >> 20) + kMinBorder; ky = (int)((jkey[q] >> 8) & 0xFFF) + kMinBorder;
     };
@@ -1054,19 +1054,21 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         const DevLevel& L = lv[jlevel[q]];
         int kx, ky; key_xy(q, kx, ky);
         // blurred window rows ky-18..ky+18, the four 16-byte columns from the one holding column kx-18, out of the
-        // tiled level: tile (y >> 3, column) holds row y at byte 16 * (y & 7)
+        // tiled level: tile (y >> 3, column) holds row y at byte 16 * (y & 7).  The 192 slots of the three loads walk
+        // the memory order -- column, tile row (six cover the 37 rows wherever they start), row inside the tile -- so every
+        // aligned group of four lanes reads 64 contiguous bytes; slots outside the window stay idle.
         const uint8_t* bsrc = blr + (unsigned long long)frame * blur_bytes + L.blur_offset + 128u * (uint32_t)((kx - 18) >> 4);
         const uint32_t tile_row_bytes = 128u * (uint32_t)L.tpr;
-        auto tiled = [&](uint32_t r, uint32_t col16) __attribute__((always_inline)) {
-            const uint32_t y = (uint32_t)(ky - 18) + r;
-            return __umul24(y >> 3, tile_row_bytes) + 16u * (y & 7u) + 8u * col16;   // col16 = 16 * column index
+        const uint32_t ytile = (uint32_t)(ky - 18) >> 3, off7 = (uint32_t)(ky - 18) & 7u;
+        auto tiled = [&](int k) __attribute__((always_inline)) {
+            return __umul24(ytile + (wrem[k] >> 3), tile_row_bytes) + 128u * wcol[k] + 16u * (wrem[k] & 7u);
         };
         // the 37 columns start at byte (kx-18) & 15 of the first chunk: the fourth chunk of a row is only touched when
         // that offset is 12 or more (a quarter of the keypoints)
-        const uint32_t last = ((uint32_t)(kx - 18) & 15u) >= 12u ? 64u : 48u;
-        if (wcol[0] < last) f.w0 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[0], wcol[0]));
-        if (wcol[1] < last) f.w1 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[1], wcol[1]));
-        if (lane + 128 < kBlurW * kWinChunks && wcol[2] < last) f.w2 = *reinterpret_cast<const u32x4*>(bsrc + tiled(wrow[2], wcol[2]));
+        const uint32_t last = ((uint32_t)(kx - 18) & 15u) >= 12u ? 4u : 3u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (wrem[k] - off7 < (uint32_t)kBlurW && wcol[k] < last) f.w[k] = *reinterpret_cast<const u32x4*>(bsrc + tiled(k));
     };
     // IC_Angle (src/ORBextractor.cc:76-103): integer moments over the 749-pixel disc, four pixels per
     // v_dot4_u32_u8.  m10 = sum u*I = sum (u+16)*I - 16*sum I,  m01 = sum v*I; bytes outside the disc have weight 0.
@@ -1106,9 +1108,12 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         if (jlevel[q] < 0) return;
         wave_sync();        // the previous keypoint's tests have read the window
         u32x4* winv = reinterpret_cast<u32x4*>(win);
-        winv[lane] = f.w0;
-        winv[lane + 64] = f.w1;
-        if (lane + 128 < kBlurW * kWinChunks) winv[lane + 128] = f.w2;
+        int kx, ky; key_xy(q, kx, ky);
+        const uint32_t off7 = (uint32_t)(ky - 18) & 7u;
+        const uint32_t last = ((uint32_t)(kx - 18) & 15u) >= 12u ? 4u : 3u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (wrem[k] - off7 < (uint32_t)kBlurW && wcol[k] < last) winv[(wrem[k] - off7) * kWinChunks + wcol[k]] = f.w[k];
     };
     auto process = [&](int q) __attribute__((always_inline)) {
         if (jlevel[q] < 0) return;
