@@ -937,6 +937,17 @@ __device__ __forceinline__ void sincos_0_2pi(double x, double& sn, double& cs)
     cs = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
 }
 
+// Sum over the 64 lanes as a wave-uniform value: four DPP adds inside each row of 16 lanes (lane pairs, quad halves,
+// rotations by 4 and 8), then the four row sums meet in scalar registers.
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);     // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);     // row_ror:8
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 // Byte weights of the intensity-centroid sums for the eight dwords of a disc row |v| read from column u = -16:
 // wu = u + 16 inside the disc, wm = 1 inside the disc, 0 outside.
 struct IcTable { uint32_t wu[16][8]; uint32_t wm[16][8]; };
@@ -1081,7 +1092,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         }
         m10 = (int)su - 16 * (int)sm;                      // lanes outside the disc hold zero weights
         m01 = cv * (int)sm;
-        for (int s = 32; s >= 1; s >>= 1) { m10 += __shfl_xor(m10, s, 64); m01 += __shfl_xor(m01, s, 64); }
+        m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
     };
     static_assert(kKpPerWave == 4, "the schedule below is written out for four keypoints");
     u32x4 disc[kKpPerWave];
