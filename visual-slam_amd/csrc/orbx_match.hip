@@ -80,6 +80,115 @@ __global__ __launch_bounds__(kBlock) void k_best2(const uint32_t* __restrict__ q
     }
 }
 
+// The same search on the matrix cores.  With a map row t as 256 bytes of 0 / 1 and a query q as 256 bytes of +1 (bit clear)
+// / -1 (bit set), the integer dot product is popc(t) - 2 popc(q & t), so distance(q, t) = popc(q) + dot: an exact int8
+// contraction, v_mfma_i32_32x32x32_i8 (8 per 32 rows x 32 queries, 32 cycles each: four times the pairs per clock of the
+// xor / popcount form).  A wavefront owns a run of map rows and kMfmaQT tiles of 32 queries (their +-1 bytes stay in
+// registers); per tile of 32 rows each lane expands 16 bits of its row per k-step (nibble * 0x00204081 & 0x01010101) as the
+// A operand.  D has the query on the lane and 16 rows in the registers: the tile's smallest dot is compared with the
+// lane's current second-best first (8 v_min3), and only a tile that can change a lane's result walks its 16 keys
+// (distance << 22 | row, as in k_best2).  Lanes l and l + 32 hold the same queries over different rows and merge at the end.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int kMfmaQT = 4;                         // query tiles of 32 per wavefront
+constexpr int kMfmaQueries = 32 * kMfmaQT;         // queries per workgroup (its four waves share them over different rows)
+
+__device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t nib) { return __umul24(nib, 0x00204081u) & 0x01010101u; }   // nib < 16
+__device__ __forceinline__ v4i bits16_to_bytes(uint32_t hw)                                                                // hw < 65536
+{
+    v4i a;
+    a.x = (int)bits4_to_bytes(hw & 15u);
+    a.y = (int)bits4_to_bytes((hw >> 4) & 15u);
+    a.z = (int)bits4_to_bytes((hw >> 8) & 15u);
+    a.w = (int)bits4_to_bytes(hw >> 12);
+    return a;
+}
+
+// grid: (ceil(nchunks / 4), query tiles of kMfmaQueries); wave w of block x owns chunk 4 x + w
+__global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ t, long long nt,
+                                                       int rows_per_chunk, int nchunks, Part* __restrict__ parts)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, half = lane >> 5;
+    const int chunk = blockIdx.x * 4 + wave;
+    if (chunk >= nchunks) return;
+    const long long r0 = (long long)chunk * rows_per_chunk;
+    const int nrows = (int)min((long long)rows_per_chunk, nt - r0);
+    const uint32_t hshift = 16u * (uint32_t)half;
+
+    v4i B[kMfmaQT][8];
+    int pq[kMfmaQT], thr[kMfmaQT];
+    uint32_t best[kMfmaQT], second[kMfmaQT];
+#pragma unroll
+    for (int qt = 0; qt < kMfmaQT; ++qt) {
+        const int qi = min((int)blockIdx.y * kMfmaQueries + qt * 32 + n, nq - 1);
+        const uint4 lo = *reinterpret_cast<const uint4*>(q + (size_t)qi * 8), hi = *reinterpret_cast<const uint4*>(q + (size_t)qi * 8 + 4);
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        int p = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            p += __popc(w[s]);
+            const v4i e = bits16_to_bytes((w[s] >> hshift) & 0xFFFFu);
+            // bit set -> -1 (0xFF), bit clear -> +1
+            B[qt][s].x = (int)(((uint32_t)e.x * 0xFEu) | 0x01010101u); B[qt][s].y = (int)(((uint32_t)e.y * 0xFEu) | 0x01010101u);
+            B[qt][s].z = (int)(((uint32_t)e.z * 0xFEu) | 0x01010101u); B[qt][s].w = (int)(((uint32_t)e.w * 0xFEu) | 0x01010101u);
+        }
+        pq[qt] = p; thr[qt] = 256 - p;
+        best[qt] = kKeyInit; second[qt] = kKeyInit;
+    }
+
+    const uint32_t* rows = t + (size_t)r0 * 8;
+    uint4 nlo, nhi;
+    {
+        const uint32_t* rp = rows + (size_t)min(n, nrows - 1) * 8;
+        nlo = *reinterpret_cast<const uint4*>(rp); nhi = *reinterpret_cast<const uint4*>(rp + 4);
+    }
+    for (int tb = 0; tb < nrows; tb += 32) {
+        const uint32_t w[8] = {nlo.x, nlo.y, nlo.z, nlo.w, nhi.x, nhi.y, nhi.z, nhi.w};
+        {
+            const uint32_t* rp = rows + (size_t)min(tb + 32 + n, nrows - 1) * 8;      // next tile (rows past the end repeat the last row)
+            nlo = *reinterpret_cast<const uint4*>(rp); nhi = *reinterpret_cast<const uint4*>(rp + 4);
+        }
+        v16i acc[kMfmaQT];
+        const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const v4i a = bits16_to_bytes((w[s] >> hshift) & 0xFFFFu);
+#pragma unroll
+            for (int qt = 0; qt < kMfmaQT; ++qt) acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[qt][s], s == 0 ? zero : acc[qt], 0, 0, 0);
+        }
+        const bool tail = tb + 32 > nrows;
+        const uint32_t rowbase = (uint32_t)tb + 4u * (uint32_t)half;         // register j holds row rowbase + (j & 3) + 8 (j >> 2)
+#pragma unroll
+        for (int qt = 0; qt < kMfmaQT; ++qt) {
+            const v16i& d = acc[qt];
+            int m = min(min(d[0], d[1]), d[2]);
+            m = min(min(m, d[3]), d[4]); m = min(min(m, d[5]), d[6]); m = min(min(m, d[7]), d[8]);
+            m = min(min(m, d[9]), d[10]); m = min(min(m, d[11]), d[12]); m = min(min(m, d[13]), d[14]);
+            m = min(m, d[15]);
+            if (__any(m <= thr[qt]) || tail) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t r = rowbase + (uint32_t)((j & 3) + 8 * (j >> 2));
+                    uint32_t key = ((uint32_t)(d[j] + pq[qt]) << kIdxBits) + r;
+                    if (tail && r >= (uint32_t)nrows) key = kKeyInit;
+                    second[qt] = med3u(best[qt], second[qt], key);
+                    best[qt] = min(best[qt], key);
+                }
+                thr[qt] = (int)(second[qt] >> kIdxBits) - pq[qt];
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < kMfmaQT; ++qt) {
+        const uint32_t ob = __shfl_xor(best[qt], 32, 64), os = __shfl_xor(second[qt], 32, 64);
+        const uint32_t b = min(best[qt], ob), s2 = min(max(best[qt], ob), min(second[qt], os));
+        const int qi = (int)blockIdx.y * kMfmaQueries + qt * 32 + n;
+        if (half == 0 && qi < nq) { Part p; p.best = b; p.second = s2; parts[(size_t)chunk * nq + qi] = p; }
+    }
+}
+
 // one thread per query: fold the per-chunk partial results in chunk (= index) order
 __global__ __launch_bounds__(256) void k_best2_fold(const Part* __restrict__ parts, int nchunks, int nq, int rows_per_chunk,
                                                     long long index_base, orbx_best2* __restrict__ out)
@@ -352,12 +461,14 @@ static int reserve(void** p, size_t* have, size_t need)
     return ORBX_OK;
 }
 
+// Row runs of the matrix-core kernel: one per wavefront, a multiple of 32 rows, enough of them to give every SIMD two waves,
+// and as long as that allows (a lane's second-best tightens with the rows it has seen, and fewer tiles walk their keys).
 static void chunking(int nq, int64_t nt, int& rows_per_chunk, int& nchunks)
 {
-    const int qtiles = (nq + kBlock * kQPT - 1) / (kBlock * kQPT);
-    int64_t want = std::max<int64_t>(1, 4096 / std::max(qtiles, 1));     // enough workgroups to fill 256 CUs several times
+    const int qtiles = (nq + kMfmaQueries - 1) / kMfmaQueries;
+    const int64_t want = std::max<int64_t>(4, (2048 + qtiles - 1) / std::max(qtiles, 1));
     int64_t rpc = (nt + want - 1) / want;
-    rpc = std::max<int64_t>(rpc, 256);
+    rpc = std::max<int64_t>((rpc + 31) & ~(int64_t)31, 256);
     rpc = std::min<int64_t>(rpc, (1 << kIdxBits));
     rows_per_chunk = (int)rpc;
     nchunks = (int)((nt + rpc - 1) / rpc);
@@ -414,11 +525,11 @@ int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const
     chunking(nq, nt, rpc, nch);
     int rc = reserve(&m->ws, &m->ws_bytes, sizeof(Part) * (size_t)nch * nq);
     if (rc) return rc;
-    const int qtiles = (nq + kBlock * kQPT - 1) / (kBlock * kQPT);
+    const int qtiles = (nq + kMfmaQueries - 1) / kMfmaQueries;
     if (nt == 0) nch = 0;
     if (nch > 0)
-        hipLaunchKernelGGL(k_best2, dim3(nch, qtiles), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(d_q), nq,
-                           reinterpret_cast<const uint32_t*>(d_t), (long long)nt, rpc, reinterpret_cast<Part*>(m->ws));
+        hipLaunchKernelGGL(k_best2_mfma, dim3((nch + 3) / 4, qtiles), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(d_q), nq,
+                           reinterpret_cast<const uint32_t*>(d_t), (long long)nt, rpc, nch, reinterpret_cast<Part*>(m->ws));
     hipLaunchKernelGGL(k_best2_fold, dim3((nq + 255) / 256), dim3(256), 0, st, reinterpret_cast<const Part*>(m->ws), nch, nq, rpc,
                        (long long)index_base, d_out);
     HIP_CHECK(hipGetLastError());
