@@ -82,95 +82,98 @@ __global__ __launch_bounds__(kBlock) void k_best2(const uint32_t* __restrict__ q
 
 // The same search on the matrix cores.  With a map row t as 256 bytes of 0 / 1 and a query q as 256 bytes of +1 (bit clear)
 // / -1 (bit set), the integer dot product is popc(t) - 2 popc(q & t), so distance(q, t) = popc(q) + dot: an exact int8
-// contraction, v_mfma_i32_32x32x32_i8 (8 per 32 rows x 32 queries, 32 cycles each: four times the pairs per clock of the
-// xor / popcount form).  A wavefront owns a run of map rows and kMfmaQT tiles of 32 queries (their +-1 bytes stay in
-// registers); per tile of 32 rows each lane expands 16 bits of its row per k-step (nibble * 0x00204081 & 0x01010101) as the
-// A operand.  D has the query on the lane and 16 rows in the registers: the tile's smallest dot is compared with the
-// lane's current second-best first (8 v_min3), and only a tile that can change a lane's result walks its 16 keys
-// (distance << 22 | row, as in k_best2).  Lanes l and l + 32 hold the same queries over different rows and merge at the end.
+// contraction, v_mfma_i32_16x16x64_i8 (4 per 16 rows x 16 queries, 16 cycles each: four times the pairs per clock of the
+// xor / popcount form).  A wavefront owns a run of map rows and kMfmaQT tiles of 16 queries (their +-1 bytes stay in
+// registers); per tile of 16 rows each lane expands 16 bits of its row per k-step (nibble * 0x00204081 & 0x01010101) as the
+// A operand.  The order of the 256 bit positions inside the contraction is free as long as both operands agree: lane group
+// g = lane >> 4 takes bytes 8 g .. 8 g + 7 of its row or query (one 8-byte load), k-step s the s-th 16 bits of them.
+// D has the query on the lane and 4 rows in the registers: the tile's smallest dot is compared with the lane's current
+// second-best first, and only a tile that can change a lane's result walks its 4 keys (distance << 22 | row, as in
+// k_best2).  The four lane groups hold the same queries over different rows and merge at the end.
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-constexpr int kMfmaQT = 4;                         // query tiles of 32 per wavefront
-constexpr int kMfmaQueries = 32 * kMfmaQT;         // queries per workgroup (its four waves share them over different rows)
+constexpr int kMfmaQT = 8;                         // query tiles of 16 per wavefront
+constexpr int kMfmaQueries = 16 * kMfmaQT;         // queries per workgroup (its four waves share them over different rows)
 
 __device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t nib) { return __umul24(nib, 0x00204081u) & 0x01010101u; }   // nib < 16
-__device__ __forceinline__ v4i bits16_to_bytes(uint32_t hw)                                                                // hw < 65536
+template <int HALF> __device__ __forceinline__ v4i bits16_to_bytes(uint32_t w)      // the low (HALF 0) or high 16 bits of w
 {
     v4i a;
-    a.x = (int)bits4_to_bytes(hw & 15u);
-    a.y = (int)bits4_to_bytes((hw >> 4) & 15u);
-    a.z = (int)bits4_to_bytes((hw >> 8) & 15u);
-    a.w = (int)bits4_to_bytes(hw >> 12);
+    a.x = (int)bits4_to_bytes((w >> (16 * HALF)) & 15u);
+    a.y = (int)bits4_to_bytes((w >> (16 * HALF + 4)) & 15u);
+    a.z = (int)bits4_to_bytes((w >> (16 * HALF + 8)) & 15u);
+    a.w = (int)bits4_to_bytes((w >> (16 * HALF + 12)) & 15u);
     return a;
 }
 
 // grid: (ceil(nchunks / 4), query tiles of kMfmaQueries); wave w of block x owns chunk 4 x + w
 __global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ t, long long nt,
-                                                       int rows_per_chunk, int nchunks, Part* __restrict__ parts)
+                                                          int rows_per_chunk, int nchunks, Part* __restrict__ parts)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, half = lane >> 5;
+    const int n = lane & 15, grp = lane >> 4;
+    // byte -> its eight bits as bytes of 0 / 1, for the row expansion in the loop (two LDS reads per 16 bits instead of
+    // twelve vector instructions: the vector pipe is what the loop has least of)
+    __shared__ uint2 s_lut[256];
+    s_lut[threadIdx.x] = make_uint2(bits4_to_bytes(threadIdx.x & 15u), bits4_to_bytes(threadIdx.x >> 4));
+    __syncthreads();
     const int chunk = blockIdx.x * 4 + wave;
     if (chunk >= nchunks) return;
     const long long r0 = (long long)chunk * rows_per_chunk;
     const int nrows = (int)min((long long)rows_per_chunk, nt - r0);
-    const uint32_t hshift = 16u * (uint32_t)half;
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut);
 
-    v4i B[kMfmaQT][8];
+    v4i B[kMfmaQT][4];
     int pq[kMfmaQT], thr[kMfmaQT];
     uint32_t best[kMfmaQT], second[kMfmaQT];
 #pragma unroll
     for (int qt = 0; qt < kMfmaQT; ++qt) {
-        const int qi = min((int)blockIdx.y * kMfmaQueries + qt * 32 + n, nq - 1);
+        const int qi = min((int)blockIdx.y * kMfmaQueries + qt * 16 + n, nq - 1);
         const uint4 lo = *reinterpret_cast<const uint4*>(q + (size_t)qi * 8), hi = *reinterpret_cast<const uint4*>(q + (size_t)qi * 8 + 4);
-        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        int p = 0;
+        pq[qt] = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
+        const uint2 mine = *reinterpret_cast<const uint2*>(q + (size_t)qi * 8 + 2 * grp);
+        const uint32_t w[2] = {mine.x, mine.y};
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            p += __popc(w[s]);
-            const v4i e = bits16_to_bytes((w[s] >> hshift) & 0xFFFFu);
+        for (int s = 0; s < 4; ++s) {
+            const v4i e = (s & 1) ? bits16_to_bytes<1>(w[s >> 1]) : bits16_to_bytes<0>(w[s >> 1]);
             // bit set -> -1 (0xFF), bit clear -> +1
             B[qt][s].x = (int)(((uint32_t)e.x * 0xFEu) | 0x01010101u); B[qt][s].y = (int)(((uint32_t)e.y * 0xFEu) | 0x01010101u);
             B[qt][s].z = (int)(((uint32_t)e.z * 0xFEu) | 0x01010101u); B[qt][s].w = (int)(((uint32_t)e.w * 0xFEu) | 0x01010101u);
         }
-        pq[qt] = p; thr[qt] = 256 - p;
+        thr[qt] = 256 - pq[qt];
         best[qt] = kKeyInit; second[qt] = kKeyInit;
     }
 
-    const uint32_t* rows = t + (size_t)r0 * 8;
-    uint4 nlo, nhi;
-    {
-        const uint32_t* rp = rows + (size_t)min(n, nrows - 1) * 8;
-        nlo = *reinterpret_cast<const uint4*>(rp); nhi = *reinterpret_cast<const uint4*>(rp + 4);
-    }
-    for (int tb = 0; tb < nrows; tb += 32) {
-        const uint32_t w[8] = {nlo.x, nlo.y, nlo.z, nlo.w, nhi.x, nhi.y, nhi.z, nhi.w};
-        {
-            const uint32_t* rp = rows + (size_t)min(tb + 32 + n, nrows - 1) * 8;      // next tile (rows past the end repeat the last row)
-            nlo = *reinterpret_cast<const uint4*>(rp); nhi = *reinterpret_cast<const uint4*>(rp + 4);
-        }
-        v16i acc[kMfmaQT];
-        const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // rows: lane (n, grp) reads bytes 8 grp .. 8 grp + 7 of row tb + n, two tiles ahead of the tile being multiplied
+    // (rows past the end of the run repeat its last row)
+    const uint32_t* rows = t + (size_t)r0 * 8 + 2 * grp;
+    auto row_at = [&](int r) __attribute__((always_inline)) { return *reinterpret_cast<const uint2*>(rows + (size_t)min(r, nrows - 1) * 8); };
+    uint2 n1 = row_at(n), n2 = row_at(16 + n);
+    for (int tb = 0; tb < nrows; tb += 16) {
+        const uint32_t w[2] = {n1.x, n1.y};
+        n1 = n2;
+        n2 = row_at(tb + 32 + n);
+        v4i acc[kMfmaQT];
+        const v4i zero = {0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const v4i a = bits16_to_bytes((w[s] >> hshift) & 0xFFFFu);
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t ws = w[s >> 1];
+            const uint2 e0 = *reinterpret_cast<const uint2*>(lut + (s & 1 ? (ws >> 13) & 0x7F8u : (ws << 3) & 0x7F8u));
+            const uint2 e1 = *reinterpret_cast<const uint2*>(lut + (s & 1 ? (ws >> 21) & 0x7F8u : (ws >> 5) & 0x7F8u));
+            const v4i a = {(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
 #pragma unroll
-            for (int qt = 0; qt < kMfmaQT; ++qt) acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B[qt][s], s == 0 ? zero : acc[qt], 0, 0, 0);
+            for (int qt = 0; qt < kMfmaQT; ++qt) acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, B[qt][s], s == 0 ? zero : acc[qt], 0, 0, 0);
         }
-        const bool tail = tb + 32 > nrows;
-        const uint32_t rowbase = (uint32_t)tb + 4u * (uint32_t)half;         // register j holds row rowbase + (j & 3) + 8 (j >> 2)
+        const bool tail = tb + 16 > nrows;
+        const uint32_t rowbase = (uint32_t)tb + 4u * (uint32_t)grp;          // register j holds row rowbase + j
 #pragma unroll
         for (int qt = 0; qt < kMfmaQT; ++qt) {
-            const v16i& d = acc[qt];
-            int m = min(min(d[0], d[1]), d[2]);
-            m = min(min(m, d[3]), d[4]); m = min(min(m, d[5]), d[6]); m = min(min(m, d[7]), d[8]);
-            m = min(min(m, d[9]), d[10]); m = min(min(m, d[11]), d[12]); m = min(min(m, d[13]), d[14]);
-            m = min(m, d[15]);
+            const v4i& d = acc[qt];
+            const int m = min(min(d[0], d[1]), min(d[2], d[3]));
             if (__any(m <= thr[qt]) || tail) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t r = rowbase + (uint32_t)((j & 3) + 8 * (j >> 2));
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t r = rowbase + (uint32_t)j;
                     uint32_t key = ((uint32_t)(d[j] + pq[qt]) << kIdxBits) + r;
                     if (tail && r >= (uint32_t)nrows) key = kKeyInit;
                     second[qt] = med3u(best[qt], second[qt], key);
@@ -182,10 +185,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __rest
     }
 #pragma unroll
     for (int qt = 0; qt < kMfmaQT; ++qt) {
-        const uint32_t ob = __shfl_xor(best[qt], 32, 64), os = __shfl_xor(second[qt], 32, 64);
-        const uint32_t b = min(best[qt], ob), s2 = min(max(best[qt], ob), min(second[qt], os));
-        const int qi = (int)blockIdx.y * kMfmaQueries + qt * 32 + n;
-        if (half == 0 && qi < nq) { Part p; p.best = b; p.second = s2; parts[(size_t)chunk * nq + qi] = p; }
+        uint32_t b = best[qt], s2 = second[qt];
+#pragma unroll
+        for (int x = 16; x <= 32; x <<= 1) {
+            const uint32_t ob = __shfl_xor(b, x, 64), os = __shfl_xor(s2, x, 64);
+            s2 = min(max(b, ob), min(s2, os));
+            b = min(b, ob);
+        }
+        const int qi = (int)blockIdx.y * kMfmaQueries + qt * 16 + n;
+        if (grp == 0 && qi < nq) { Part p; p.best = b; p.second = s2; parts[(size_t)chunk * nq + qi] = p; }
     }
 }
 
