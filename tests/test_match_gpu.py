@@ -63,6 +63,20 @@ def test_best2_ties_and_extremes(vsa, oracle, matcher):
     assert eq_best2(got, oracle.hamming_best2(one, ~one))
 
 
+@pytest.mark.parametrize("nt", [15, 16, 17, 255, 4099, 70001])
+def test_best2_few_patterns(vsa, oracle, matcher, nt):
+    """Rows and queries drawn from a handful of patterns (all zeros, all ones, a nibble pattern, a random row, its
+    complement and a one-bit neighbour): nearly every comparison is a tie, so the lowest-index rule and the second-best of
+    equal distances are exercised across every tile, lane group and row-run boundary; distances 0 and 256 both occur."""
+    rng = np.random.default_rng(nt)
+    a = rng.integers(0, 256, 32, dtype=np.uint8)
+    a1 = a.copy(); a1[7] ^= 0x10
+    pats = np.stack([np.zeros(32, np.uint8), np.full(32, 255, np.uint8), np.full(32, 0x0F, np.uint8), a, ~a, a1])
+    table = pats[rng.integers(0, len(pats), nt)]
+    q = np.concatenate([pats, pats[rng.integers(0, len(pats), 125)], rng.integers(0, 256, (9, 32), dtype=np.uint8)])
+    assert eq_best2(matcher.hamming_best2(q, table), oracle.hamming_best2(q, table))
+
+
 def test_best2_empty_table(vsa, matcher):
     q = vsa.synth_descriptors(1, 5)
     got = matcher.hamming_best2(q, np.zeros((0, 32), np.uint8))

@@ -2,10 +2,9 @@
 // (src/ORBmatcher.cc:1650-1666 DescriptorDistance and the best / second-best bookkeeping of the
 // Search* routines) and of Frame::ComputeStereoMatches (src/Frame.cc:466-549).
 //
-// Distances are 8 x (v_xor_b32 + v_bcnt_u32_b32) per pair; nothing here is a dense contraction, so
-// no MFMA.  The brute-force kernel keeps queries in VGPRs and streams map rows through scalar
-// registers (every lane of a wave compares against the same row), so a pair costs 16 vector
-// lane-operations plus three for the running best / second-best.
+// The windowed and row-band searches take distances as 8 x (v_xor_b32 + v_bcnt_u32_b32) per pair.  The brute-force
+// search against a large map is the one dense contraction of the library (every query against every row): it runs on
+// the matrix cores as an exact int8 product (k_best2_mfma below).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <cmath>
@@ -29,7 +28,6 @@ namespace {
 
 constexpr int kIdxBits = 22;                       // row index inside a chunk
 constexpr uint32_t kKeyInit = 256u << kIdxBits;    // distance 256, never beaten by a real row (strict '<')
-constexpr int kQPT = 2;                            // queries per thread
 constexpr int kBlock = 256;
 
 struct Part { uint32_t best, second; };            // packed keys: distance << 22 | row-in-chunk
@@ -39,57 +37,16 @@ __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c)
     return max(min(a, b), min(max(a, b), c));      // folds to v_med3_u32
 }
 
-// grid: (chunks, query tiles).  Thread t of tile y owns queries y*512 + t and y*512 + 256 + t.
-__global__ __launch_bounds__(kBlock) void k_best2(const uint32_t* __restrict__ q, int nq,
-                                                  const uint32_t* __restrict__ t, long long nt,
-                                                  int rows_per_chunk, Part* __restrict__ parts)
-{
-    const int tid = threadIdx.x;
-    const int q0 = blockIdx.y * (kBlock * kQPT) + tid;
-    uint32_t qv[kQPT][8];
-    uint32_t best[kQPT], second[kQPT];
-#pragma unroll
-    for (int j = 0; j < kQPT; ++j) {
-        const int qi = min(q0 + j * kBlock, nq - 1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qv[j][i] = q[(size_t)qi * 8 + i];
-        best[j] = kKeyInit; second[j] = kKeyInit;
-    }
-    const long long r0 = (long long)blockIdx.x * rows_per_chunk;
-    const int nrows = (int)min((long long)rows_per_chunk, nt - r0);
-    const uint32_t* row = t + (size_t)r0 * 8;
-#pragma unroll 4
-    for (int r = 0; r < nrows; ++r, row += 8) {
-        uint32_t m[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) m[i] = row[i];          // wave-uniform address: scalar load
-#pragma unroll
-        for (int j = 0; j < kQPT; ++j) {
-            uint32_t d = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) d += __popc(qv[j][i] ^ m[i]);
-            const uint32_t key = (d << kIdxBits) + (uint32_t)r;
-            second[j] = med3u(best[j], second[j], key);
-            best[j] = min(best[j], key);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kQPT; ++j) {
-        const int qi = q0 + j * kBlock;
-        if (qi < nq) { Part p; p.best = best[j]; p.second = second[j]; parts[(size_t)blockIdx.x * nq + qi] = p; }
-    }
-}
-
-// The same search on the matrix cores.  With a map row t as 256 bytes of 0 / 1 and a query q as 256 bytes of +1 (bit clear)
+// Brute-force best / second-best on the matrix cores.  With a map row t as 256 bytes of 0 / 1 and a query q as 256 bytes of +1 (bit clear)
 // / -1 (bit set), the integer dot product is popc(t) - 2 popc(q & t), so distance(q, t) = popc(q) + dot: an exact int8
 // contraction, v_mfma_i32_16x16x64_i8 (4 per 16 rows x 16 queries, 16 cycles each: four times the pairs per clock of the
-// xor / popcount form).  A wavefront owns a run of map rows and kMfmaQT tiles of 16 queries (their +-1 bytes stay in
+// xor / popcount form, which needs 19 vector instructions per 64 pairs).  A wavefront owns a run of map rows and kMfmaQT tiles of 16 queries (their +-1 bytes stay in
 // registers); per tile of 16 rows each lane expands 16 bits of its row per k-step (nibble * 0x00204081 & 0x01010101) as the
 // A operand.  The order of the 256 bit positions inside the contraction is free as long as both operands agree: lane group
 // g = lane >> 4 takes bytes 8 g .. 8 g + 7 of its row or query (one 8-byte load), k-step s the s-th 16 bits of them.
 // D has the query on the lane and 4 rows in the registers: the tile's smallest dot is compared with the lane's current
-// second-best first, and only a tile that can change a lane's result walks its 4 keys (distance << 22 | row, as in
-// k_best2).  The four lane groups hold the same queries over different rows and merge at the end.
+// second-best first, and only a tile that can change a lane's result walks its 4 keys (distance << 22 | row-in-run: the
+// minimum over keys is the lowest distance and, on ties, the lowest row).  The four lane groups hold the same queries over different rows and merge at the end.
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kMfmaQT = 8;                         // query tiles of 16 per wavefront
 constexpr int kMfmaQueries = 16 * kMfmaQT;         // queries per workgroup (its four waves share them over different rows)
