@@ -63,7 +63,7 @@ def test_best2_ties_and_extremes(vsa, oracle, matcher):
     assert eq_best2(got, oracle.hamming_best2(one, ~one))
 
 
-@pytest.mark.parametrize("nt", [15, 16, 17, 255, 4099, 70001])
+@pytest.mark.parametrize("nt", [15, 16, 17, 255, 4099, 70001, 300001])     # the last one takes the seeded two-pass route
 def test_best2_few_patterns(vsa, oracle, matcher, nt):
     """Rows and queries drawn from a handful of patterns (all zeros, all ones, a nibble pattern, a random row, its
     complement and a one-bit neighbour): nearly every comparison is a tie, so the lowest-index rule and the second-best of
@@ -74,6 +74,20 @@ def test_best2_few_patterns(vsa, oracle, matcher, nt):
     pats = np.stack([np.zeros(32, np.uint8), np.full(32, 255, np.uint8), np.full(32, 0x0F, np.uint8), a, ~a, a1])
     table = pats[rng.integers(0, len(pats), nt)]
     q = np.concatenate([pats, pats[rng.integers(0, len(pats), 125)], rng.integers(0, 256, (9, 32), dtype=np.uint8)])
+    assert eq_best2(matcher.hamming_best2(q, table), oracle.hamming_best2(q, table))
+
+
+def test_best2_seeded_pass_late_winners(vsa, oracle, matcher):
+    """Large map whose best rows lie far behind the rows the threshold seed is taken from, some of them exact duplicates
+    of each other: the seeded pass must still find them, lowest index first."""
+    nt, nq = 400_000, 200
+    table = vsa.synth_descriptors(77, nt)
+    q = vsa.synth_descriptors(78, nq)
+    rng = np.random.default_rng(5)
+    for i in range(nq):                               # plant near-copies of the queries at the back of the map
+        for pos in rng.integers(nt // 2, nt, 3):
+            row = q[i].copy(); row[rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8)) if i % 3 else np.uint8(0)
+            table[pos] = row
     assert eq_best2(matcher.hamming_best2(q, table), oracle.hamming_best2(q, table))
 
 

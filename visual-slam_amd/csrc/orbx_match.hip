@@ -64,7 +64,8 @@ template <int HALF> __device__ __forceinline__ v4i bits16_to_bytes(uint32_t w)  
 
 // grid: (ceil(nchunks / 4), query tiles of kMfmaQueries); wave w of block x owns chunk 4 x + w
 __global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ t, long long nt,
-                                                          int rows_per_chunk, int nchunks, Part* __restrict__ parts)
+                                                          int rows_per_chunk, int nchunks, const orbx_best2* __restrict__ seed,
+                                                          Part* __restrict__ parts)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __rest
             B[qt][s].x = (int)(((uint32_t)e.x * 0xFEu) | 0x01010101u); B[qt][s].y = (int)(((uint32_t)e.y * 0xFEu) | 0x01010101u);
             B[qt][s].z = (int)(((uint32_t)e.z * 0xFEu) | 0x01010101u); B[qt][s].w = (int)(((uint32_t)e.w * 0xFEu) | 0x01010101u);
         }
-        thr[qt] = 256 - pq[qt];
+        // with a seed (the second-best distance over a sample of the rows) only rows that can still matter are ever walked
+        thr[qt] = (seed ? seed[qi].second : 256) - pq[qt];
         best[qt] = kKeyInit; second[qt] = kKeyInit;
     }
 
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __rest
                     second[qt] = med3u(best[qt], second[qt], key);
                     best[qt] = min(best[qt], key);
                 }
-                thr[qt] = (int)(second[qt] >> kIdxBits) - pq[qt];
+                thr[qt] = min(thr[qt], (int)(second[qt] >> kIdxBits) - pq[qt]);
             }
         }
     }
@@ -411,6 +413,7 @@ struct orbx_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
     void* ws = nullptr; size_t ws_bytes = 0;       // partial results of the brute-force kernel
+    void* seed = nullptr; size_t seed_bytes = 0;   // its per-query result over the first rows (threshold seed of the full pass)
     void* stage[8] = {}; size_t stage_bytes[8] = {}; // staging buffers of the host entry points
     void* win = nullptr; size_t win_bytes = 0;       // device arena of the windowed candidate generation
     uint8_t* pin = nullptr; size_t pin_bytes = 0;    // pinned host mirror of it (one upload, two small downloads per call)
@@ -465,6 +468,7 @@ void orbx_matcher_destroy(orbx_matcher* m)
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->ws) (void)hipFree(m->ws);
+    if (m->seed) (void)hipFree(m->seed);
     for (void* p : m->stage) if (p) (void)hipFree(p);
     if (m->win) (void)hipFree(m->win);
     if (m->pin) (void)hipHostFree(m->pin);
@@ -474,9 +478,10 @@ void orbx_matcher_destroy(orbx_matcher* m)
 
 int64_t orbx_hamming_best2_workspace_bytes(int nq, int64_t nt)
 {
-    int rpc, nch;
+    int rpc, nch, rpc1, nch1;
     chunking(nq, nt, rpc, nch);
-    return (int64_t)sizeof(Part) * nch * nq;
+    chunking(nq, std::min<int64_t>(nt, 16384), rpc1, nch1);      // the seeding pass of large maps
+    return (int64_t)sizeof(Part) * std::max(nch, nch1) * nq + (int64_t)sizeof(orbx_best2) * nq;
 }
 
 int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt, int64_t index_base,
@@ -488,13 +493,29 @@ int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const
     hipStream_t st = (hipStream_t)stream;
     int rpc, nch;
     chunking(nq, nt, rpc, nch);
-    int rc = reserve(&m->ws, &m->ws_bytes, sizeof(Part) * (size_t)nch * nq);
+    // Large maps: a first pass over the first kSeedRows rows gives every query a second-best distance that no row of the final
+    // answer exceeds; seeded with it, the full pass walks the keys of few tiles instead of warming every row run up from 256.
+    constexpr int64_t kSeedRows = 16384;
+    const bool seeded = nt >= 16 * kSeedRows;
+    int rpc1 = 0, nch1 = 0;
+    if (seeded) chunking(nq, kSeedRows, rpc1, nch1);
+    int rc = reserve(&m->ws, &m->ws_bytes, sizeof(Part) * (size_t)std::max(nch, nch1) * nq);
     if (rc) return rc;
     const int qtiles = (nq + kMfmaQueries - 1) / kMfmaQueries;
+    const orbx_best2* d_seed = nullptr;
+    if (seeded) {
+        if ((rc = reserve(&m->seed, &m->seed_bytes, sizeof(orbx_best2) * (size_t)nq))) return rc;
+        hipLaunchKernelGGL(k_best2_mfma, dim3((nch1 + 3) / 4, qtiles), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(d_q), nq,
+                           reinterpret_cast<const uint32_t*>(d_t), (long long)kSeedRows, rpc1, nch1, (const orbx_best2*)nullptr,
+                           reinterpret_cast<Part*>(m->ws));
+        hipLaunchKernelGGL(k_best2_fold, dim3((nq + 255) / 256), dim3(256), 0, st, reinterpret_cast<const Part*>(m->ws), nch1, nq, rpc1,
+                           0LL, reinterpret_cast<orbx_best2*>(m->seed));
+        d_seed = reinterpret_cast<const orbx_best2*>(m->seed);
+    }
     if (nt == 0) nch = 0;
     if (nch > 0)
         hipLaunchKernelGGL(k_best2_mfma, dim3((nch + 3) / 4, qtiles), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(d_q), nq,
-                           reinterpret_cast<const uint32_t*>(d_t), (long long)nt, rpc, nch, reinterpret_cast<Part*>(m->ws));
+                           reinterpret_cast<const uint32_t*>(d_t), (long long)nt, rpc, nch, d_seed, reinterpret_cast<Part*>(m->ws));
     hipLaunchKernelGGL(k_best2_fold, dim3((nq + 255) / 256), dim3(256), 0, st, reinterpret_cast<const Part*>(m->ws), nch, nq, rpc,
                        (long long)index_base, d_out);
     HIP_CHECK(hipGetLastError());
