@@ -163,7 +163,10 @@ void orbx_compute_three_maxima(const int32_t* sizes, int L, int* ind1, int* ind2
 
 /* Best / second-best Hamming distance of every query over a whole descriptor set, with the
  * sequential loop's semantics (strict '<': lowest index wins ties; start values 256 / -1 / 256),
- * i.e. the inner loop of every Search* routine (e.g. src/ORBmatcher.cc:439-460) without a window. */
+ * i.e. the inner loop of every Search* routine (e.g. src/ORBmatcher.cc:439-460) without a window.
+ * Runs on the matrix cores as an exact int8 product (distance = popc(q) + dot of the query's +-1 bytes with the row's
+ * 0/1 bytes).  d_q must be 16-byte aligned, d_t 8-byte aligned (ORBX_ERR_BAD_ARG otherwise).  The matcher's scratch is shared by its calls: calls on one
+ * matcher must not overlap in time (use one matcher per stream). */
 int orbx_hamming_best2(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int64_t nt, orbx_best2* out);
 int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
                               int64_t index_base, orbx_best2* d_out, void* stream);

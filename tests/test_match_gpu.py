@@ -91,6 +91,21 @@ def test_best2_seeded_pass_late_winners(vsa, oracle, matcher):
     assert eq_best2(matcher.hamming_best2(q, table), oracle.hamming_best2(q, table))
 
 
+def test_best2_rejects_misaligned_pointers(vsa, matcher):
+    """The matrix-core kernel reads 16-byte (queries) and 8-byte (rows) vectors: other alignments are refused on the host."""
+    import torch
+    buf = torch.zeros(64 * 32 + 64, dtype=torch.uint8, device="cuda")
+    out = torch.zeros((4, 4), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(vsa.OrbxError):
+        matcher.hamming_best2_device(buf.data_ptr() + 8, 4, buf.data_ptr(), 16, 0, out.data_ptr(), st)
+    with pytest.raises(vsa.OrbxError):
+        matcher.hamming_best2_device(buf.data_ptr(), 4, buf.data_ptr() + 4, 16, 0, out.data_ptr(), st)
+    matcher.hamming_best2_device(buf.data_ptr() + 16, 4, buf.data_ptr() + 8, 16, 0, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert (out[:, 0] == 0).all().item() and (out[:, 1] == 0).all().item()
+
+
 def test_best2_empty_table(vsa, matcher):
     q = vsa.synth_descriptors(1, 5)
     got = matcher.hamming_best2(q, np.zeros((0, 32), np.uint8))

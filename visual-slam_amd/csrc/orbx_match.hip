@@ -489,6 +489,8 @@ int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const
 {
     if (!m || !d_q || !d_out || nq < 1 || nt < 0 || (nt > 0 && !d_t)) { set_error("orbx_hamming_best2_device: bad argument"); return ORBX_ERR_BAD_ARG; }
     if (index_base + nt > 0x7FFFFFFFLL) { set_error("global row index exceeds int32"); return ORBX_ERR_BAD_ARG; }
+    // the kernel reads queries as 16-byte and rows as 8-byte vectors
+    if (((uintptr_t)d_q & 15u) || ((uintptr_t)d_t & 7u)) { set_error("orbx_hamming_best2_device: queries must be 16-byte aligned, map rows 8-byte aligned"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipSetDevice(m->device));
     hipStream_t st = (hipStream_t)stream;
     int rpc, nch;
