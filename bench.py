@@ -36,8 +36,8 @@ MFMA_OPS_PER_PAIR = 512                    # 256 int8 multiply-accumulates: dist
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--contexts", type=int, default=8,
                     help="extractor contexts per GPU, each on its own HIP stream with batch/contexts frames "
