@@ -34,13 +34,26 @@ static inline void ot_count(int* base, int idx) { if (idx >= 0) base[idx] += 1; 
 static __device__ __forceinline__ int ot_atomic_add(int* p, int v) { return atomicAdd(p, v); }
 static __device__ __forceinline__ unsigned ot_atomic_max(unsigned* p, unsigned v) { return atomicMax(p, v); }
 static __device__ __forceinline__ float ot_fdiv(float a, float b) { return __fdiv_rn(a, b); }
+// Inclusive prefix sum over the 64 lanes (all active) with DPP adds: shifts by 1, 2, 4, 8 inside each row of 16 lanes (a lane
+// without a source adds 0), then the last lane of row 0 / 2 into row 1 / 3 and lane 31 into rows 2 and 3.  Six dependent
+// vector instructions instead of six LDS round trips through ds_bpermute.
+static __device__ __forceinline__ int ot_wave_scan_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
 // base[idx] += 1 for every lane with idx >= 0.  Every lane of the wavefront must call it (idx < 0: nothing to
 // add).  Keys are stored in raster order, so neighbouring lanes mostly hit the same node and quadrant: each
 // run of equal targets adds once, with the run's length, instead of up to 64 same-address atomics.
 static __device__ __forceinline__ void ot_count(int* base, int idx)
 {
     const int lane = threadIdx.x & 63;
-    const int prev = __shfl_up(idx, 1, 64);
+    const int prev = __builtin_amdgcn_update_dpp(idx, idx, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps its own, and is a head anyway)
     const bool head = lane == 0 || idx != prev;
     const unsigned long long m = __ballot(head);
     const unsigned long long above = lane == 63 ? 0ull : m >> (lane + 1);
@@ -90,8 +103,7 @@ static OT_DEV int ot_block_scan(int32_t* a, int n, int32_t* tmp)
         // one element per thread: wave-level scan, then the totals of the waves in front
         const int lane1 = tid & 63, wave1 = tid >> 6;
         const int v = tid < n ? a[tid] : 0;
-        int inc1 = v;
-        for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc1, d, 64); if (lane1 >= d) inc1 += o; }
+        const int inc1 = ot_wave_scan_incl(v);
         if (lane1 == 63) tmp[wave1] = inc1;
         __syncthreads();
         const int nw1 = (nt + 63) >> 6;
@@ -107,8 +119,7 @@ static OT_DEV int ot_block_scan(int32_t* a, int n, int32_t* tmp)
     for (int i = b; i < e; ++i) sum += a[i];
     // inclusive scan of per-thread sums inside the wave
     const int lane = tid & 63, wave = tid >> 6;
-    int inc = sum;
-    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    const int inc = ot_wave_scan_incl(sum);
     if (lane == 63) tmp[wave] = inc;
     __syncthreads();
     const int nw = (nt + 63) >> 6;

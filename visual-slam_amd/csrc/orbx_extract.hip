@@ -614,9 +614,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         wave_sync();
     }
     const int cnt = __popcll(mask);
-    int inc = cnt;
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-    const int total = __shfl(inc, 63, 64);
+    const int inc = ot_wave_scan_incl(cnt);
+    const int total = __builtin_amdgcn_readlane(inc, 63);
     int pos = inc - cnt;
     uint32_t* out = cand + (unsigned long long)frame * cand_total + L.cand_offset + c.slot;
     while (mask) {
