@@ -62,6 +62,18 @@ typedef unsigned short us16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return *reinterpret_cast<const u32_unaligned*>(p); }
 
+// Sum over the 64 lanes as a wave-uniform value: four DPP adds inside each row of 16 lanes (lane pairs, quad halves,
+// rotations by 4 and 8), then the four row sums meet in scalar registers.
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);     // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);     // row_ror:8
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+
 // LDS hand-off between the lanes of one wavefront: DS operations of a wave execute in issue order,
 // so only the compiler has to be kept from moving accesses across this point.
 __device__ __forceinline__ void wave_sync()
@@ -715,7 +727,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
     // number of candidates of this level: decides where the key arrays live
     int part = 0;
     for (int i = tid; i < L.cell_count; i += NT) part += cnt[i];
-    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    part = wave_sum_i32(part);
     if (tid == 0) s_nk = 0;
     __syncthreads();
     if ((tid & 63) == 0) atomicAdd(&s_nk, part);
@@ -934,17 +946,6 @@ __device__ __forceinline__ void sincos_0_2pi(double x, double& sn, double& cs)
     const int n = (int)k & 3;
     sn = (n == 0) ? s : (n == 1) ? c : (n == 2) ? -s : -c;
     cs = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
-}
-
-// Sum over the 64 lanes as a wave-uniform value: four DPP adds inside each row of 16 lanes (lane pairs, quad halves,
-// rotations by 4 and 8), then the four row sums meet in scalar registers.
-__device__ __forceinline__ int wave_sum_i32(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm:[1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm:[2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);     // row_ror:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);     // row_ror:8
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
 // Byte weights of the intensity-centroid sums for the eight dwords of a disc row |v| read from column u = -16:
@@ -1223,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_stereo_refine(const uint8_t* __restrict
             }
 #pragma unroll
             for (int i = 0; i <= 2 * R; ++i)
-                for (int d = 32; d >= 1; d >>= 1) acc[i] += __shfl_xor(acc[i], d, 64);
+                acc[i] = wave_sum_i32(acc[i]);
             int bestDist = 2147483647, bestinc = 0;
 #pragma unroll
             for (int i = 0; i <= 2 * R; ++i) if (acc[i] < bestDist) { bestDist = acc[i]; bestinc = i - R; }
@@ -1262,7 +1263,7 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict
     const size_t base = (size_t)pair * cap;
     int nv = 0;
     for (int i = lane; i < nl; i += 64) nv += sad[base + i] >= 0;
-    for (int d = 32; d >= 1; d >>= 1) nv += __shfl_xor(nv, d, 64);
+    nv = wave_sum_i32(nv);
     if (nv == 0) return;
     const int kth = nv / 2;
     int lo = 0, hi = 1 << 16;                               // least v with #{s : 0 <= s <= v} > kth; an 11x11 SAD is at most 30 855
@@ -1270,7 +1271,7 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict
         const int v = lo + ((hi - lo) >> 1);
         int cnt = 0;
         for (int i = lane; i < nl; i += 64) { const int sv = sad[base + i]; cnt += sv >= 0 && sv <= v; }
-        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        cnt = wave_sum_i32(cnt);
         if (cnt > kth) hi = v; else lo = v + 1;
     }
     const float thDist = 1.5f * 1.4f * (float)lo;
