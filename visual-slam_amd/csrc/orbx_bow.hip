@@ -102,10 +102,11 @@ __global__ __launch_bounds__(256) void k_voc_descend(const uint32_t* __restrict_
             const uint4 lo = slot_desc[2 * (size_t)(first + c)], hi = slot_desc[2 * (size_t)(first + c) + 1];
             key = min(key, ((uint32_t)hamming256(q, lo, hi) << 16) | (uint32_t)c);
         }
-        key = min(key, (uint32_t)__shfl_xor((int)key, 1, 16));
-        key = min(key, (uint32_t)__shfl_xor((int)key, 2, 16));
-        key = min(key, (uint32_t)__shfl_xor((int)key, 4, 16));
-        key = min(key, (uint32_t)__shfl_xor((int)key, 8, 16));
+        // minimum over the feature's 16 lanes (one DPP row): lane pairs, quad halves, rotations by 4 and 8
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xF, 0xF, false));    // quad_perm:[1,0,3,2]
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x4E, 0xF, 0xF, false));    // quad_perm:[2,3,0,1]
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x124, 0xF, 0xF, false));   // row_ror:4
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x128, 0xF, 0xF, false));   // row_ror:8
         cur = slot_node[first + (int)(key & 0xFFFFu)];
         if (++level == nid_level) nid = cur;
         first = child_first[cur];
