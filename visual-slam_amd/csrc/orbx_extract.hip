@@ -558,10 +558,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         rowmask[lane] = 0;
         wave_sync();
         const s16x2 thr1 = {(short)(T + 1), (short)(T + 1)};
-        int nq = 0, nsq = 0;                            // wave-uniform queue fills
-        for (int y0 = 0; y0 < ch; y0 += rows_per_round) {
+        // pass 1: every lane keeps the survivors of its four pixels per round as a nibble of its own bit set (round r in bits
+        // 4r..4r+3; nibble bit k is pixel {0, 2, 1, 3}[k] of the group): nothing is queued while the rounds run
+        unsigned long long mybits = 0;
+        int round = 0;
+        for (int y0 = 0; y0 < ch; y0 += rows_per_round, ++round) {
             const int y = y0 + lrow;
-            uint32_t pm = 0;
             if (y < ch && colmask) {
                 const uint32_t* row = reinterpret_cast<const uint32_t*>(&tile[y * TS]) + g;   // tile row y = image row y-3
                 constexpr int RS = TS / 4;
@@ -573,42 +575,46 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                 // margin - (T + 1) is non-negative (sign bit clear) exactly for the survivors
                 const uint32_t q01 = as_u32(fast_pretest<0>(m3, m2, cc, p2, p3) - thr1);
                 const uint32_t q23 = as_u32(fast_pretest<2>(m3, m2, cc, p2, p3) - thr1);
-                pm = (((q01 & 0x80008000u) ^ 0x80008000u) >> 15) | (((q23 & 0x80008000u) ^ 0x80008000u) >> 14);
+                uint32_t pm = (((q01 & 0x80008000u) ^ 0x80008000u) >> 15) | (((q23 & 0x80008000u) ^ 0x80008000u) >> 14);
                 pm &= colmask;
-            }
-            // queue the survivors of this round (wave-level compaction, one ballot per pixel slot)
-            const int idx = y * 64 + x;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool on = (pm >> ((j >> 1) + 16 * (j & 1))) & 1u;
-                const unsigned long long m = __ballot(on);
-                if (on) queue[nsq + nq + lanes_below(m)] = (uint16_t)(idx + j);
-                nq += __popcll(m);
-            }
-            if (nq >= 192 || y0 + rows_per_round >= ch) {
-                // pass 2: exact score of the queued survivors; corners go to the score tile and the scored list
-                // (a scored entry is written at or below the slot its lane just read, so no waiting entry is overwritten)
-                wave_sync();
-                const int first = nsq;
-                for (int e0 = 0; e0 < nq; e0 += 64) {
-                    const int e = e0 + lane;
-                    bool keep = false;
-                    int i = 0;
-                    if (e < nq) {
-                        i = queue[first + e];
-                        const int yy = i >> 6, xx = i & 63;
-                        const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
-                        keep = sc >= T;
-                        if (keep) score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
-                    }
-                    const unsigned long long m = __ballot(keep);
-                    if (keep) queue[nsq + lanes_below(m)] = (uint16_t)i;
-                    nsq += __popcll(m);
-                }
-                wave_sync();
-                nq = 0;
+                mybits |= (unsigned long long)((pm & 3u) | ((pm >> 14) & 0xCu)) << (4 * round);
             }
         }
+        // the survivors of the whole cell go to the queue in one step: a prefix sum of the lanes' counts, then every lane
+        // writes its own (the order inside the queue does not matter)
+        int nq, nsq = 0;
+        {
+            const int mine = __popcll(mybits);
+            const int incl = ot_wave_scan_incl(mine);
+            nq = __builtin_amdgcn_readlane(incl, 63);
+            int off = incl - mine;
+            const int base = lrow * 64 + x;
+            while (mybits) {
+                const int bpos = __ffsll((long long)mybits) - 1;
+                mybits &= mybits - 1;
+                const int k = bpos & 3;
+                queue[off++] = (uint16_t)(base + (bpos >> 2) * (rows_per_round * 64) + (((k & 1) << 1) | (k >> 1)));
+            }
+        }
+        // pass 2: exact score of the queued survivors; corners go to the score tile and the scored list
+        // (a scored entry is written at or below the slot its lane just read, so no waiting entry is overwritten)
+        wave_sync();
+        for (int e0 = 0; e0 < nq; e0 += 64) {
+            const int e = e0 + lane;
+            bool keep = false;
+            int i = 0;
+            if (e < nq) {
+                i = queue[e];
+                const int yy = i >> 6, xx = i & 63;
+                const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
+                keep = sc >= T;
+                if (keep) score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) queue[nsq + lanes_below(m)] = (uint16_t)i;
+            nsq += __popcll(m);
+        }
+        wave_sync();
         // pass 3: strict local maxima inside the cell among the corners, one lane per corner; row masks of the maxima
         for (int e = lane; e < nsq; e += 64) {
             const int i = queue[e];
