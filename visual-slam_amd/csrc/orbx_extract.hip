@@ -9,6 +9,7 @@
 //   k_blur        7x7 Gaussian of every level                      :1084-1085
 //   k_describe    IC angle, rBRIEF on the blurred level, output record  :76-146, :1086-1102
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -560,7 +561,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         const s16x2 thr1 = {(short)(T + 1), (short)(T + 1)};
         // pass 1: every lane keeps the survivors of its four pixels per round as a nibble of its own bit set (round r in bits
         // 4r..4r+3; nibble bit k is pixel {0, 2, 1, 3}[k] of the group): nothing is queued while the rounds run
-        unsigned long long mybits = 0;
+        // (cells of the small variant take at most seven rounds: 32 bits hold them)
+        typedef typename std::conditional<(TR <= kSmallCellDim + 6), uint32_t, unsigned long long>::type Bits;
+        static_assert(TR > kSmallCellDim + 6 || (kSmallCellDim + 5) / (64 / ((kSmallCellDim + 3) / 4)) + 1 <= 8, "rounds of a small cell must fit 32 bits");
+        Bits mybits = 0;
         int round = 0;
         for (int y0 = 0; y0 < ch; y0 += rows_per_round, ++round) {
             const int y = y0 + lrow;
@@ -577,20 +581,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                 const uint32_t q23 = as_u32(fast_pretest<2>(m3, m2, cc, p2, p3) - thr1);
                 uint32_t pm = (((q01 & 0x80008000u) ^ 0x80008000u) >> 15) | (((q23 & 0x80008000u) ^ 0x80008000u) >> 14);
                 pm &= colmask;
-                mybits |= (unsigned long long)((pm & 3u) | ((pm >> 14) & 0xCu)) << (4 * round);
+                mybits |= (Bits)((pm & 3u) | ((pm >> 14) & 0xCu)) << (4 * round);
             }
         }
         // the survivors of the whole cell go to the queue in one step: a prefix sum of the lanes' counts, then every lane
         // writes its own (the order inside the queue does not matter)
         int nq, nsq = 0;
         {
-            const int mine = __popcll(mybits);
+            const int mine = __popcll((unsigned long long)mybits);
             const int incl = ot_wave_scan_incl(mine);
             nq = __builtin_amdgcn_readlane(incl, 63);
             int off = incl - mine;
             const int base = lrow * 64 + x;
             while (mybits) {
-                const int bpos = __ffsll((long long)mybits) - 1;
+                const int bpos = sizeof(Bits) == 4 ? __ffs((int)mybits) - 1 : __ffsll((long long)mybits) - 1;
                 mybits &= mybits - 1;
                 const int k = bpos & 3;
                 queue[off++] = (uint16_t)(base + (bpos >> 2) * (rows_per_round * 64) + (((k & 1) << 1) | (k >> 1)));
