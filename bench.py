@@ -3,37 +3,39 @@
 
   python bench.py --gpus N --steps K --warmup W
 
+With N > 1 and no WORLD_SIZE in the environment this process only launches: it starts N fresh rank processes
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU each), relays rank 0's JSON line and exits with their status.
+It imports neither torch nor the library and makes no HIP call itself.  Under `python -m torch.distributed.run` the
+ranks exist already and every process is a worker.
+
 One "step" is one pass of the hot path over one batch of synthetic input per GPU:
-  * ORBextractor::operator() over a batch of 640x480 frames (1000 keypoints, 8 levels) -- `value`,
-  * brute-force Hamming best-2 of 4096 queries against one 2^21-row map shard (the per-GPU share
-    of the 2^24-row map when it is sharded over 8 GPUs) plus, for N>1, the RCCL all-gather of the
-    per-rank top-2 and its merge -- reported under "hamming".
-Inputs are resident in HBM before the timed region.  Frames are sharded over ranks with no
-collective (weak scaling: per-GPU batch fixed); the map is sharded over ranks with one all-gather.
-Rank 0 prints one JSON line.
+  * headline (`value`): ORBextractor::operator() over a batch of 640x480 frames (1000 keypoints, 8 levels); frames are
+    sharded over ranks with no collective, per-GPU batch fixed (weak scaling);
+  * `configs`: the other workloads of the baseline sheet, each timed the same way --
+      stereo_752x480      left + right extraction, row-band Hamming search, SAD refinement (pairs/s; replicas per GPU),
+      kitti_1241x376      a fixed batch of 4096 frames, 2000 features, split over the ranks (strong scaling),
+      uhd_3840x2160       8000 features, 12 levels (replicas per GPU),
+  * `hamming`: brute-force best-2 of 4096 queries against a 2^24-row map split over the ranks; for N > 1 followed by
+    the RCCL all-gather of the per-rank top-2 and its merge (strong scaling; N = 1 holds the whole map).
+Inputs are resident in HBM before every timed region.  Rank 0 prints one JSON line.
 """
 import argparse
-import importlib
 import json
 import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-vsa = importlib.import_module("visual-slam_amd")
 
 HBM_PEAK = 8.0e12                          # bytes/s, MI355X HBM3E
 VALU_PEAK = 256 * 64 * 2.4e9               # lane-ops/s: 256 CUs x 64 lanes x 2.4 GHz
 OPS_PER_PAIR = 16                          # xor / popcount form: 8 x v_xor_b32 + 8 x v_bcnt_u32_b32
 MFMA_I8_PEAK = 1024 * 2048 * 2.4e9         # int8 op/s, dense: 1024 SIMDs x 2048 op/clk (v_mfma_i32_16x16x64_i8: 32768 op in 16 clk) x 2.4 GHz
 MFMA_OPS_PER_PAIR = 512                    # 256 int8 multiply-accumulates: distance = popc(q) + dot(+-1 bytes of q, 0/1 bytes of row)
+MAP_CHUNKS = 8                             # the 2^24-row map is 8 chunks of 2^21 rows, chunk c drawn from PCG32(42 + c)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -47,82 +49,379 @@ def parse():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--nlevels", type=int, default=8)
     ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--map-rows-per-gpu", type=int, default=1 << 21)
+    ap.add_argument("--map-rows", type=int, default=1 << 24, help="rows of the whole map (split over the ranks)")
+    ap.add_argument("--kitti-frames", type=int, default=4096, help="frames of the strong-scaling 1241x376 batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true", help="skip the stereo / 1241x376 / 3840x2160 legs")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry", action="store_true",
+                    help="no GPU work: ranks rendezvous, exchange and merge stand-in records (launcher / collective rehearsal on CPU)")
+    return ap.parse_args(argv)
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
+def hip_mapped():
+    """True when this process has a HIP runtime or the library mapped (the launching parent must not)."""
+    with open("/proc/self/maps") as f:
+        maps = f.read()
+    return any(k in maps for k in ("libamdhip64", "liborbx", "libhsa-runtime"))
+
+
+# ---------------------------------------------------------------------------------------------- launcher
+def launch(a, argv):
+    import socket
+    import subprocess
+    import threading
+    assert not hip_mapped() and "torch" not in sys.modules, "the launching process must stay clear of the GPU runtime"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        time.sleep(0.1)
+    if failed is None:
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:                      # a rank died: the others would wait in a collective for ever
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with status {failed[1]}\n")
+        sys.exit(1)
+    reader.join(timeout=10)
+    out = None
+    for ln in lines:
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                out = json.loads(ln)
+            except ValueError:
+                pass
+        elif ln:
+            sys.stderr.write(ln + "\n")
+    if out is None:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        sys.exit(1)
+    out["launcher"] = {"spawned": a.gpus, "by": "bench.py", "parent_touched_hip": hip_mapped()}
+    print(json.dumps(out))
+
+
+# ---------------------------------------------------------------------------------------------- worker
+class Ctx:
+    """Rank plumbing: barrier + device synchronise on both sides of a timed region, MAX over ranks of its duration."""
+
+    def __init__(self, a):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dry = a.dry
+        self.dist = None
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-    n_gpus = world
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if a.backend == "nccl" and not a.dry:
+                dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device(f"cuda:{self.local}"))
+            else:
+                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+        if not a.dry:
+            torch.cuda.set_device(self.local)
+            self.dev = torch.device(f"cuda:{self.local}")
+        else:
+            self.dev = torch.device("cpu")
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize()
 
-    def max_over_ranks(x):
-        if dist is None:
+    def barrier(self):
+        self.sync()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ------------------------------------------------------------------ extraction workload
+    def sum_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def ranks_seen(self):
+        """All-gather of the rank ids: the record shows how many ranks the collective backend really connected."""
+        if self.dist is None:
+            return [0]
+        mine = self.torch.tensor([self.rank], dtype=self.torch.int32, device=self.dev)
+        got = self.torch.zeros(self.world, dtype=self.torch.int32, device=self.dev)
+        self.dist.all_gather_into_tensor(got, mine)
+        return [int(v) for v in got.cpu().tolist()]
+
+    def timed(self, step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+
+def alg_bytes_per_image(vsa, p, W, H, mean_kp):
+    """Algorithmic bytes of one ORBextractor call: pyramid read + write, FAST read, blur read + write over the sum of the
+    level areas, and per keypoint a 749-byte orientation disc, a 37x37 descriptor window and 60 bytes of output."""
+    sum_p = sum(w * h for w, h in (vsa.level_size(p, W, H, l) for l in range(p.nlevels)))
+    return sum_p, 5 * sum_p + mean_kp * 2178
+
+
+class ExtractJob:
+    """n_frames HBM-resident frames of one shape spread over `contexts` extractor contexts / HIP streams; a context
+    takes its share in launches of at most `chunk` frames."""
+
+    def __init__(self, cx, vsa, np, p, W, H, n_frames, contexts, chunk, seed0, stereo_right=None, n_unique=32):
+        torch = cx.torch
+        self.cx, self.vsa, self.p, self.W, self.H, self.n = cx, vsa, p, W, H, n_frames
+        C = max(1, min(contexts, n_frames))
+        self.per = (n_frames + C - 1) // C
+        self.chunk = max(1, min(chunk, self.per))
+        self.exs = [vsa.Extractor(p, W, H, max_batch=self.chunk, device=cx.local) for _ in range(C)]
+        self.streams = [torch.cuda.Stream(device=cx.dev) for _ in range(C)]
+        self.cap = self.exs[0].cap
+        n_unique = min(n_frames, n_unique)
+        if stereo_right is None:
+            uniq = np.stack([vsa.synth_frame(seed0 + i, W, H) for i in range(n_unique)])
+        else:
+            uniq = np.stack([vsa.synth_stereo(seed0 + i, W, H)[1 if stereo_right else 0] for i in range(n_unique)])
+        self.uniq = uniq
+        reps = (n_frames + n_unique - 1) // n_unique
+        self.frames = torch.from_numpy(uniq).to(cx.dev).repeat(reps, 1, 1)[:n_frames].contiguous()
+        self.kps = torch.zeros((n_frames, self.cap, 7), dtype=torch.float32, device=cx.dev)
+        self.desc = torch.zeros((n_frames, self.cap, 32), dtype=torch.uint8, device=cx.dev)
+        self.counts = torch.zeros(n_frames, dtype=torch.int32, device=cx.dev)
+
+    def step(self):
+        W, H = self.W, self.H
+        for c, ex in enumerate(self.exs):
+            f0, f1 = c * self.per, min((c + 1) * self.per, self.n)
+            while f0 < f1:
+                nf = min(self.chunk, f1 - f0)
+                ex.extract_batch_device(self.frames[f0:].data_ptr(), W, W * H, nf, self.kps[f0:].data_ptr(), self.desc[f0:].data_ptr(),
+                                        self.counts[f0:].data_ptr(), self.cap, self.streams[c].cuda_stream)
+                f0 += nf
+
+    def mean_kp(self):
+        return float(self.counts.float().mean().item())
+
+    def close(self):
+        for e in self.exs:
+            e.close()
+        self.exs = []
+
+
+def leg_config_extract(cx, vsa, np, name, W, H, nfeatures, nlevels, frames_total, strong, contexts, chunk, steps, warmup, note):
+    """One extraction workload of the baseline sheet.  strong: frames_total is the whole job, split over the ranks
+    (orbx_shard_range); otherwise every rank runs frames_total of its own."""
+    p = vsa.make_params(nfeatures=nfeatures, nlevels=nlevels)
+    if strong:
+        b, e = vsa.shard_range(frames_total, cx.rank, cx.world)
+        n_local, job_frames = e - b, frames_total
+    else:
+        n_local, job_frames = frames_total, frames_total * cx.world
+    job = ExtractJob(cx, vsa, np, p, W, H, n_local, contexts, chunk, seed0=cx.rank * 100000 + 500, stereo_right=None, n_unique=8)
+    t = cx.timed(job.step, steps, warmup)
+    mean_kp = cx.sum_over_ranks(job.mean_kp() * n_local) / job_frames
+    job.close()
+    sum_p, a_img = alg_bytes_per_image(vsa, p, W, H, mean_kp)
+    fps = job_frames * steps / t
+    return {"name": name, "workload": note, "value": fps, "unit": "frames/s", "ms_per_step": 1e3 * t / steps, "steps": steps,
+            "frames_per_step_all_gpus": job_frames, "scaling": "strong" if strong else "weak",
+            "mean_keypoints_per_frame": round(mean_kp, 1), "alg_bytes_per_frame": int(a_img),
+            "achieved_GBps_per_gpu": round(a_img * fps / cx.world / 1e9, 1), "frac_hbm": round(a_img * fps / cx.world / HBM_PEAK, 4)}
+
+
+def leg_stereo(cx, vsa, np, steps, warmup, B=128, nfeatures=1200):
+    """BASELINE configs[1]: 752x480 pairs, left and right extraction on two contexts / streams, then the row-band Hamming
+    search (src/Frame.cc:466-549) and the sub-pixel refinement (:551-639); camera constants of Examples/Stereo/EuRoC.yaml."""
+    torch = cx.torch
+    W, H = 752, 480
+    p = vsa.make_params(nfeatures=nfeatures, nlevels=8)
+    left = ExtractJob(cx, vsa, np, p, W, H, B, 1, B, seed0=cx.rank * 100000 + 30, stereo_right=False, n_unique=16)
+    right = ExtractJob(cx, vsa, np, p, W, H, B, 1, B, seed0=cx.rank * 100000 + 30, stereo_right=True, n_unique=16)
+    m = vsa.Matcher(device=cx.local)
+    cap = left.cap
+    bd = torch.zeros((B, cap), dtype=torch.int32, device=cx.dev)
+    bi, sad = torch.zeros_like(bd), torch.zeros_like(bd)
+    ur = torch.zeros((B, cap), dtype=torch.float32, device=cx.dev)
+    dp = torch.zeros_like(ur)
+    scale = vsa.scale_tables(p)["scale"]
+    bf, fx = 47.90639384423901, 435.2046959714599
+    s0, s1 = left.streams[0], right.streams[0]
+
+    def step():
+        left.step()
+        right.step()
+        s0.wait_stream(s1)
+        m.stereo_match_batch_device(left.kps.data_ptr(), left.desc.data_ptr(), left.counts.data_ptr(), right.kps.data_ptr(),
+                                    right.desc.data_ptr(), right.counts.data_ptr(), cap, B, scale, H, 0.0, fx,
+                                    bd.data_ptr(), bi.data_ptr(), s0.cuda_stream)
+        left.exs[0].stereo_refine_batch_device(right.exs[0], left.kps.data_ptr(), left.counts.data_ptr(), right.kps.data_ptr(), cap, B,
+                                               bd.data_ptr(), bi.data_ptr(), bf, 0.0, fx, ur.data_ptr(), dp.data_ptr(), sad.data_ptr(),
+                                               s0.cuda_stream)
+        s1.wait_stream(s0)
+
+    t = cx.timed(step, steps, warmup)
+    mean_kp = 0.5 * (left.mean_kp() + right.mean_kp())
+    matched = float((ur >= 0).sum().item()) / B
+    left.close(); right.close(); m.close()
+    _, a_img = alg_bytes_per_image(vsa, p, W, H, mean_kp)
+    pps = cx.world * B * steps / t
+    return {"name": "stereo_752x480", "workload": f"{B} HBM-resident 752x480 pairs per GPU per step, nFeatures={nfeatures} (EuRoC.yaml), left + right "
+                                                  "ORBextractor on two contexts, stereo row-band Hamming search + SAD refinement",
+            "value": pps, "unit": "pairs/s", "ms_per_step": 1e3 * t / steps, "steps": steps, "scaling": "weak",
+            "mean_keypoints_per_image": round(mean_kp, 1), "mean_stereo_matches_per_pair": round(matched, 1),
+            "alg_bytes_per_pair": int(2 * a_img), "achieved_GBps_per_gpu": round(2 * a_img * pps / cx.world / 1e9, 1),
+            "frac_hbm": round(2 * a_img * pps / cx.world / HBM_PEAK, 4)}
+
+
+def leg_hamming(cx, vsa, np, a, steps, warmup):
+    """BASELINE configs[4]: 4096 queries against a 2^24-row map.  The map is MAP_CHUNKS chunks of rows; rank r holds the
+    chunks orbx_shard_range gives it, searches them in one call and, for N > 1, all-gathers its top-2 and merges."""
+    torch = cx.torch
+    nq, total = a.queries, a.map_rows
+    chunk_rows = total // MAP_CHUNKS
+    assert chunk_rows * MAP_CHUNKS == total and MAP_CHUNKS % cx.world == 0, "map rows / ranks must divide the 8 map chunks"
+    c0, c1 = vsa.shard_range(MAP_CHUNKS, cx.rank, cx.world)
+    rows = (c1 - c0) * chunk_rows
+    table = torch.empty((rows, 32), dtype=torch.uint8, device=cx.dev)
+    first = None
+    for c in range(c0, c1):
+        part_np = vsa.synth_descriptors(42 + c, chunk_rows)
+        if c == 0:
+            first = part_np
+        table[(c - c0) * chunk_rows:(c - c0 + 1) * chunk_rows].copy_(torch.from_numpy(part_np))
+    if first is None:
+        first = vsa.synth_descriptors(42, chunk_rows)
+    q_np, _ = vsa.synth_queries(43, first, nq)             # queries are noisy copies of rows of chunk 0
+    del first
+    q = torch.from_numpy(q_np).to(cx.dev)
+    m = vsa.Matcher(device=cx.local)
+    stream = torch.cuda.current_stream().cuda_stream
+    part = torch.zeros((nq, 4), dtype=torch.int32, device=cx.dev)
+    gathered = torch.zeros((cx.world * nq, 4), dtype=torch.int32, device=cx.dev)
+    merged = torch.zeros((nq, 4), dtype=torch.int32, device=cx.dev)
+
+    def step():
+        m.hamming_best2_device(q.data_ptr(), nq, table.data_ptr(), rows, c0 * chunk_rows, part.data_ptr(), stream)
+        if cx.dist is not None:
+            cx.dist.all_gather_into_tensor(gathered, part)
+            m.best2_merge_device(gathered.data_ptr(), cx.world, nq, merged.data_ptr(), stream)
+
+    t = cx.timed(step, steps, warmup)
+    res = (merged if cx.dist is not None else part).cpu().numpy()
+    m.close()
+    pps = float(nq) * total * steps / t
+    return {"metric": "Hamming pair-comparisons/s", "value": pps, "queries_per_s": nq * steps / t, "ms_per_step": 1e3 * t / steps,
+            "steps": steps, "queries": nq, "map_rows_total": total, "map_rows_per_gpu": rows, "scaling": "strong",
+            "collective": None if cx.dist is None else "all_gather_into_tensor of 16-byte top-2 records + k_best2_merge",
+            "matched_within_50": int((res[:, 0] <= 50).sum()),
+            # the search runs on the matrix cores as an exact int8 contraction; popcount_frac prices the same pairs
+            # against the vector pipe's xor / popcount issue peak (above 1: more than that formulation can reach)
+            "roofline": {"bound": "mfma", "achieved": round(MFMA_OPS_PER_PAIR * pps / cx.world / 1e12, 1),
+                         "peak": MFMA_I8_PEAK / 1e12, "unit": "TOP/s",
+                         "frac": round(MFMA_OPS_PER_PAIR * pps / cx.world / MFMA_I8_PEAK, 4),
+                         "popcount_frac": round(OPS_PER_PAIR * pps / cx.world / VALU_PEAK, 4)}}
+
+
+def dry_worker(cx, a):
+    """Rehearsal without a GPU: rendezvous, rank census, shard ranges from the library, an all-gather of stand-in top-2
+    records and the library's host merge.  What the ranks would have computed on their GPUs is replaced by a fixed
+    arithmetic pattern; launching, partitioning, exchange and merge are the real code."""
+    import importlib
+    import numpy as np
+    torch = cx.torch
+    sys.path.insert(0, ROOT)
+    vsa = importlib.import_module("visual-slam_amd")
+    seen = cx.ranks_seen()
+    nq = 64
+    fb, fe = vsa.shard_range(a.kitti_frames, cx.rank, cx.world)
+    c0, c1 = vsa.shard_range(MAP_CHUNKS, cx.rank, cx.world)
+    rec = np.zeros(nq, vsa.BEST2_DTYPE)
+    i = np.arange(nq)
+    rec["best"] = (i * 7 + cx.rank * 3) % 50
+    rec["best_idx"] = c0 * 1000 + i
+    rec["second"] = rec["best"] + 1 + cx.rank
+    mine = torch.from_numpy(rec.view(np.int32).reshape(nq, 4).copy())
+    gathered = torch.zeros((cx.world * nq, 4), dtype=torch.int32)
+    if cx.dist is not None:
+        cx.dist.all_gather_into_tensor(gathered, mine)
+    else:
+        gathered.copy_(mine)
+    merged = vsa.best2_merge(gathered.numpy().view(vsa.BEST2_DTYPE).reshape(cx.world, nq))
+    frames = cx.sum_over_ranks(fe - fb)
+    if cx.rank == 0:
+        print(json.dumps({"dry": True, "n_gpus": cx.world, "ranks_seen": seen, "frames_covered": int(frames),
+                          "frame_range_rank0": [fb, fe], "map_chunks_rank0": [c0, c1], "merge": "orbx_best2_merge",
+                          "merged_best_sum": int(merged["best"].sum()), "merged_idx_sum": int(merged["best_idx"].sum()),
+                          "merged_second_sum": int(merged["second"].sum()), "backend": "gloo"}))
+    if cx.dist is not None:
+        cx.dist.destroy_process_group()
+
+
+def worker(a):
+    import importlib
+    import numpy as np
+    if a.dry and os.environ.get("BENCH_DRY_FAIL_RANK") == os.environ.get("RANK", "0"):
+        sys.exit(3)                          # rehearsal of a rank that dies before the rendezvous (launcher test)
+    cx = Ctx(a)
+    if a.dry:
+        return dry_worker(cx, a)
+    torch = cx.torch
+    sys.path.insert(0, ROOT)
+    vsa = importlib.import_module("visual-slam_amd")
+    rank, n_gpus, dev = cx.rank, cx.world, cx.dev
+    seen = cx.ranks_seen()
+
+    # ------------------------------------------------------------------ headline: 640x480 extraction
     W, H, B = a.width, a.height, a.batch
-    C = max(1, min(a.contexts, B))
-    per = (B + C - 1) // C
     p = vsa.make_params(nfeatures=a.nfeatures, nlevels=a.nlevels)
-    exs = [vsa.Extractor(p, W, H, max_batch=per, device=local) for _ in range(C)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(C)]
-    cap = exs[0].cap
-    # distinct synthetic frames per rank (32 generated, tiled to the batch)
-    n_unique = min(B, 32)
-    uniq = np.stack([vsa.synth_frame(rank * 100000 + i, W, H) for i in range(n_unique)])
-    frames = torch.from_numpy(uniq).to(dev).repeat((B + n_unique - 1) // n_unique, 1, 1)[:B].contiguous()
-    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
-    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    counts = torch.zeros(B, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-
-    def extract_step():
-        # one pass over the GPU's batch: context c takes frames [c*per, (c+1)*per) on its own stream
-        for c in range(C):
-            f0 = c * per
-            nf = min(per, B - f0)
-            if nf > 0:
-                exs[c].extract_batch_device(frames[f0:].data_ptr(), W, W * H, nf, kps[f0:].data_ptr(), desc[f0:].data_ptr(),
-                                            counts[f0:].data_ptr(), cap, streams[c].cuda_stream)
-
-    for _ in range(a.warmup):
-        extract_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        extract_step()
-    barrier()
-    t_extract = max_over_ranks(time.perf_counter() - t0)
+    job = ExtractJob(cx, vsa, np, p, W, H, B, a.contexts, B, seed0=rank * 100000, stereo_right=None)
+    C = len(job.exs)
+    t_extract = cx.timed(job.step, a.steps, a.warmup)
     fps = n_gpus * B * a.steps / t_extract
-    mean_kp = float(counts.float().mean().item())
-    for e in exs:
-        e.close()
+    mean_kp = job.mean_kp()
+    frames, kps, desc, counts, cap, uniq = job.frames, job.kps, job.desc, job.counts, job.cap, job.uniq
+    job.close()
 
     # per-stage device time: HIP events recorded by the library on the launch stream around each stage, whole batch
     # in one context on one stream (separate steps, same workload)
-    ex = vsa.Extractor(p, W, H, max_batch=B, device=local)
+    ex = vsa.Extractor(p, W, H, max_batch=B, device=cx.local)
     stream = torch.cuda.current_stream().cuda_stream
 
     def profiled_step():
@@ -138,18 +437,10 @@ def main():
         stage_ms += ex.stage_ms()
     stage_ms /= prof_steps
     ex.set_profiling(False)
+    ex.close()
 
-    sizes = [vsa.level_size(p, W, H, l) for l in range(a.nlevels)]
-    sum_p = sum(w * h for w, h in sizes)
-    # algorithmic bytes per frame: pyramid read+write, FAST read, (blur read+write + per-keypoint
-    # orientation disc 749 B + descriptor window 1369 B + 60 B output) in the describe stage
-    stage_bytes = {
-        "pyramid": 2 * sum_p,
-        "fast": sum_p,
-        "octree": 0,
-        "describe": 2 * sum_p + mean_kp * 2178,
-    }
-    a_extract = 5 * sum_p + mean_kp * 2178
+    sum_p, a_extract = alg_bytes_per_image(vsa, p, W, H, mean_kp)
+    stage_bytes = {"pyramid": 2 * sum_p, "fast": sum_p, "octree": 0, "describe": 2 * sum_p + mean_kp * 2178}
     stages = {}
     for i, name in enumerate(vsa.STAGES):
         ms = float(stage_ms[i])
@@ -158,95 +449,51 @@ def main():
     dom = max((n for n in vsa.STAGES if stage_bytes[n] > 0), key=lambda n: stage_ms[vsa.STAGES.index(n)])
     dom_ms = float(stage_ms[vsa.STAGES.index(dom)])
     achieved = stage_bytes[dom] * B / (dom_ms * 1e-3) / 1e9
-    # HBM bytes per launch of that stage's kernels, measured with rocprofv3 --pmc on this workload (tools/pmc_traffic.py)
+    # HBM bytes per launch of that stage's kernels from the stored rocprofv3 --pmc passes (tools/pmc_traffic.py): only
+    # valid for the kernels they were taken on, so the file's build stamp must equal the loaded library's
     traffic, traffic_src, valu_issue = None, None, None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile) and (W, H, B, a.nfeatures, a.nlevels) == (640, 480, 256, 1000, 8):
         with open(tfile) as f:
             tj = json.load(f)
-        if dom in tj.get("stages", {}):
+        if tj.get("build_stamp") != vsa.build_stamp():
+            traffic_src = f"profiles/traffic.json is stale (taken on build {tj.get('build_stamp')}, library is {vsa.build_stamp()})"
+        elif dom in tj.get("stages", {}):
             traffic, traffic_src = tj["stages"][dom], tj.get("source")
-        dom_kernel = {"fast": "k_fast_cells", "octree": "k_octree"}.get(dom)
-        valu_issue = tj.get("kernels_mean_per_launch", {}).get(dom_kernel, {}).get("valu_issue_frac") if dom_kernel else None
+            dom_kernel = {"fast": "k_fast_cells", "octree": "k_octree"}.get(dom)
+            valu_issue = tj.get("kernels_mean_per_launch", {}).get(dom_kernel, {}).get("valu_issue_frac") if dom_kernel else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(stage_bytes[dom] * B), "launch_ms": round(dom_ms, 4),
                 "valu_issue_frac": valu_issue,   # measured share of cycles issuing vector ALU work: what actually bounds this kernel
                 "pipeline_alg_bytes_per_frame": int(a_extract),
                 "pipeline_frac": round(a_extract * (fps / n_gpus) / HBM_PEAK, 4)}
+    del frames, kps, desc, counts, job
 
-    ex.close()
-    stream = torch.cuda.current_stream().cuda_stream
+    # ------------------------------------------------------------------ the other workloads of the baseline sheet
+    configs = []
+    if not a.no_configs:
+        ksteps = max(2, min(a.steps, 20))
+        configs.append(leg_stereo(cx, vsa, np, ksteps, 2))
+        torch.cuda.empty_cache()
+        configs.append(leg_config_extract(cx, vsa, np, "kitti_1241x376", 1241, 376, 2000, 8, a.kitti_frames, True, 8, 128,
+                                          max(2, min(a.steps, 5)), 1,
+                                          f"one batch of {a.kitti_frames} HBM-resident 1241x376 frames, nFeatures=2000, split over the ranks "
+                                          "(BASELINE configs[2]; one step = the whole batch)"))
+        torch.cuda.empty_cache()
+        configs.append(leg_config_extract(cx, vsa, np, "uhd_3840x2160", 3840, 2160, 8000, 12, 32, False, 2, 16, max(2, min(a.steps, 10)), 1,
+                                          "32 HBM-resident 3840x2160 frames per GPU per step, nFeatures=8000, 12 levels (BASELINE configs[3])"))
+        torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ Hamming workload
     hamming = None
     if not a.no_hamming:
-        nq, rows = a.queries, a.map_rows_per_gpu
-        m = vsa.Matcher(device=local)
-        table_np = vsa.synth_descriptors(42 + rank, rows)
-        q_np, _ = vsa.synth_queries(43, vsa.synth_descriptors(42, rows), nq)   # queries come from shard 0
-        table = torch.from_numpy(table_np).to(dev)
-        q = torch.from_numpy(q_np).to(dev)
-        part = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
-        gathered = torch.zeros((n_gpus * nq, 4), dtype=torch.int32, device=dev)
-        merged = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
-
-        def match_step():
-            m.hamming_best2_device(q.data_ptr(), nq, table.data_ptr(), rows, rank * rows, part.data_ptr(), stream)
-            if dist is not None:
-                dist.all_gather_into_tensor(gathered, part)
-                m.best2_merge_device(gathered.data_ptr(), n_gpus, nq, merged.data_ptr(), stream)
-
-        for _ in range(a.warmup):
-            match_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            match_step()
-        barrier()
-        t_match = max_over_ranks(time.perf_counter() - t0)
-        pairs = float(nq) * rows * n_gpus * a.steps
-        pps = pairs / t_match
-        hamming = {"metric": "Hamming pair-comparisons/s", "value": pps, "queries_per_s": nq * a.steps / t_match,
-                   "ms_per_step": 1e3 * t_match / a.steps, "queries": nq, "map_rows_total": rows * n_gpus,
-                   # the search runs on the matrix cores as an exact int8 contraction; popcount_frac prices the same pairs
-                   # against the vector pipe's xor / popcount issue peak (above 1: more than that formulation can reach)
-                   "roofline": {"bound": "mfma", "achieved": round(MFMA_OPS_PER_PAIR * pps / n_gpus / 1e12, 1),
-                                "peak": MFMA_I8_PEAK / 1e12, "unit": "TOP/s",
-                                "frac": round(MFMA_OPS_PER_PAIR * pps / n_gpus / MFMA_I8_PEAK, 4),
-                                "popcount_frac": round(OPS_PER_PAIR * pps / n_gpus / VALU_PEAK, 4)}}
-        m.close()
+        hamming = leg_hamming(cx, vsa, np, a, max(2, min(a.steps, 40)), min(a.warmup, 3))
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     cpu = None
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as orc
-        oex = orc.Extractor(orc.make_params(nfeatures=a.nfeatures, nlevels=a.nlevels))
-        n_cpu = 0
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 12.0 and n_cpu < 400:
-            oex.extract(uniq[n_cpu % n_unique])
-            n_cpu += 1
-        dt = time.perf_counter() - t0
-        cpu = {"value": round(n_cpu / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{n_cpu} frames of the same {W}x{H}/{a.nfeatures}kp/{a.nlevels}lvl workload, CPU oracle, 1 thread "
-                         f"(host has {os.cpu_count()} logical CPUs)"}
-        # the same oracle frame-parallel over the box's CPU share (one extractor per thread; the C calls release the GIL)
-        import concurrent.futures as cf
-        nthreads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1, 16))
-
-        def worker(k):
-            e = orc.Extractor(orc.make_params(nfeatures=a.nfeatures, nlevels=a.nlevels))
-            n, t_end = 0, time.perf_counter() + 6.0
-            while time.perf_counter() < t_end and n < 200:
-                e.extract(uniq[(k + n) % n_unique])
-                n += 1
-            return n
-        t0 = time.perf_counter()
-        with cf.ThreadPoolExecutor(nthreads) as pool:
-            done = sum(pool.map(worker, range(nthreads)))
-        cpu["all_cores"] = {"value": round(done / (time.perf_counter() - t0), 2), "unit": "frames/s", "cores": nthreads,
-                            "sample": f"{done} frames, one oracle extractor per thread"}
+        cpu = cpu_baseline(a, uniq, W, H)
 
     if rank == 0:
         out = {
@@ -258,11 +505,54 @@ def main():
                                    f"{B} HBM-resident frames per GPU per step (BASELINE configs[0] shape, batched)",
                        "frames_per_gpu_per_step": B, "contexts_per_gpu": C, "mean_keypoints_per_frame": round(mean_kp, 1),
                        "parallelism": f"frames sharded over {n_gpus} GPU(s), no collective"},
-            "roofline": roofline, "stages": stages, "hamming": hamming, "cpu_baseline": cpu,
+            "ranks_seen": seen, "build_stamp": vsa.build_stamp(),
+            "roofline": roofline, "stages": stages, "configs": configs, "hamming": hamming, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    if cx.dist is not None:
+        cx.dist.destroy_process_group()
+
+
+def cpu_baseline(a, uniq, W, H):
+    """The CPU oracle on the same frames, bounded to about 12 s on one thread plus 6 s on the box's CPU share."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    n_unique = len(uniq)
+    oex = orc.Extractor(orc.make_params(nfeatures=a.nfeatures, nlevels=a.nlevels))
+    n_cpu = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 12.0 and n_cpu < 400:
+        oex.extract(uniq[n_cpu % n_unique])
+        n_cpu += 1
+    dt = time.perf_counter() - t0
+    cpu = {"value": round(n_cpu / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{n_cpu} frames of the same {W}x{H}/{a.nfeatures}kp/{a.nlevels}lvl workload, CPU oracle, 1 thread "
+                     f"(host has {os.cpu_count()} logical CPUs)"}
+    # the same oracle frame-parallel over the box's CPU share (one extractor per thread; the C calls release the GIL)
+    import concurrent.futures as cf
+    nthreads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1, 16))
+
+    def one(k):
+        e = orc.Extractor(orc.make_params(nfeatures=a.nfeatures, nlevels=a.nlevels))
+        n, t_end = 0, time.perf_counter() + 6.0
+        while time.perf_counter() < t_end and n < 200:
+            e.extract(uniq[(k + n) % n_unique])
+            n += 1
+        return n
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(nthreads) as pool:
+        done = sum(pool.map(one, range(nthreads)))
+    cpu["all_cores"] = {"value": round(done / (time.perf_counter() - t0), 2), "unit": "frames/s", "cores": nthreads,
+                        "sample": f"{done} frames, one oracle extractor per thread"}
+    return cpu
+
+
+def main():
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch(a, argv)
+    worker(a)
 
 
 if __name__ == "__main__":

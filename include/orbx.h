@@ -36,6 +36,15 @@ typedef enum orbx_status {
 
 const char* orbx_status_string(int status);
 const char* orbx_last_error(void);     /* thread-local text of the last failure */
+/* Short hash of the library's sources, fixed when it is built: lets a stored counter profile say which kernels it was
+ * taken on (no counterpart in the reference). */
+const char* orbx_build_stamp(void);
+
+/* The one partition both multi-GPU paths use (no counterpart in the reference, whose only parallelism is the two
+ * extractor threads of src/Frame.cc:78-81): rank r of `world` owns units [begin, end) = [r*total/world,
+ * (r+1)*total/world) of a frame batch (no collective follows) or of the map rows of a sharded brute-force search
+ * (orbx_best2_merge* follows the all-gather).  Host-only. */
+int orbx_shard_range(int64_t total, int rank, int world, int64_t* begin, int64_t* end);
 
 /* Constructor arguments of ORBextractor (include/ORBextractor.h:83-84) plus one knob for the
  * OpenCV build the caller wants to match. */

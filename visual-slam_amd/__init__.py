@@ -57,6 +57,8 @@ _pd = C.c_ssize_t
 _SIGS = {
     "orbx_status_string": (C.c_char_p, [_i]),
     "orbx_last_error": (C.c_char_p, []),
+    "orbx_build_stamp": (C.c_char_p, []),
+    "orbx_shard_range": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "orbx_extractor_create": (_i, [C.POINTER(Params), _i, _i, _i, _i, C.POINTER(_vp)]),
     "orbx_extractor_destroy": (None, [_vp]),
     "orbx_scale_tables": (_i, [C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -142,6 +144,17 @@ def _ptr(a):
 
 def make_params(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, blur_rounding=0):
     return Params(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, blur_rounding)
+
+
+def build_stamp():
+    return lib.orbx_build_stamp().decode()
+
+
+def shard_range(total, rank, world):
+    """[begin, end) of the units rank `rank` of `world` owns (orbx_shard_range)."""
+    b, e = _i64(), _i64()
+    _check(lib.orbx_shard_range(total, rank, world, C.byref(b), C.byref(e)))
+    return b.value, e.value
 
 
 def scale_tables(p):

@@ -377,6 +377,21 @@ const char* orbx_status_string(int s)
 
 const char* orbx_last_error(void) { return g_last_error.c_str(); }
 
+#ifndef ORBX_BUILD_STAMP
+#define ORBX_BUILD_STAMP "unstamped"
+#endif
+const char* orbx_build_stamp(void) { return ORBX_BUILD_STAMP; }
+
+// Contiguous split of `total` units (frames of a batch, rows of a descriptor map) over `world` ranks: rank r owns
+// [r*total/world, (r+1)*total/world), so the ranges tile [0, total) in rank order and differ in size by at most one.
+int orbx_shard_range(int64_t total, int rank, int world, int64_t* begin, int64_t* end)
+{
+    if (total < 0 || world < 1 || rank < 0 || rank >= world || !begin || !end) { set_error("orbx_shard_range: bad argument"); return ORBX_ERR_BAD_ARG; }
+    *begin = (int64_t)(((__int128)total * rank) / world);
+    *end = (int64_t)(((__int128)total * (rank + 1)) / world);
+    return ORBX_OK;
+}
+
 int orbx_scale_tables(const orbx_params* p, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
                       int32_t* features_per_level, int32_t* umax16)
 {
