@@ -179,6 +179,16 @@ void orbx_compute_three_maxima(const int32_t* sizes, int L, int* ind1, int* ind2
 int orbx_hamming_best2(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int64_t nt, orbx_best2* out);
 int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
                               int64_t index_base, orbx_best2* d_out, void* stream);
+/* No counterpart in the reference.  orbx_hamming_best2_device for callers that cannot allocate device memory: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same results; the kernels'
+ * scratch (per-run partial results and the seed records of the two-pass search) is a fixed array in the library's device
+ * image (4 MiB + 256 KiB, held by every GPU the library runs on for the life of the process) whose address on the matcher's
+ * device was resolved at orbx_matcher_create.  The call itself makes no hipMalloc / hipFree.  Limits: nq <= 16384 and
+ * orbx_hamming_best2_workspace_bytes(nq, nt) - 16 * nq <= 4 MiB (the row-run split keeps this near 2 MiB for every map
+ * size at nq <= 16384; e.g. 4096 x 2^24 fits); beyond them ORBX_ERR_CAPACITY.  All calls on one GPU share the array, whichever matcher they
+ * go through: calls that overlap in time on one GPU race (also with different streams); serialise them. */
+int orbx_hamming_best2_device_static(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
+                                     int64_t index_base, orbx_best2* d_out, void* stream);
 /* Merge per-shard results (ranks x nq records, shard-major; best_idx already global) into nq records:
  * the step after the RCCL all-gather when the map is sharded over GPUs. */
 int orbx_best2_merge_device(orbx_matcher* m, const orbx_best2* d_parts, int n_parts, int nq, orbx_best2* d_out, void* stream);

@@ -1,0 +1,63 @@
+"""orbx_hamming_best2_device_static (the entry point that allocates nothing: its scratch is a fixed array in the library's
+device image) against orbx_hamming_best2_device, bit for bit, through the C ABI: two calls in a row on one matcher, the
+second with a smaller input, so records the first call left in the shared scratch must not leak into the second."""
+import importlib
+
+import numpy as np
+import pytest
+
+vsa = importlib.import_module("visual-slam_amd")
+pytestmark = pytest.mark.gpu
+
+
+def _both(m, torch, q_np, t_np, index_base):
+    dev = torch.device("cuda:0")
+    q = torch.from_numpy(q_np).to(dev)
+    t = torch.from_numpy(t_np).to(dev)
+    nq, nt = q_np.shape[0], t_np.shape[0]
+    ref = torch.full((nq, 4), -7, dtype=torch.int32, device=dev)
+    got = torch.full((nq, 4), -9, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    m.hamming_best2_device(q.data_ptr(), nq, t.data_ptr(), nt, index_base, ref.data_ptr(), stream)
+    torch.cuda.synchronize()
+    before = (torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0])      # torch's allocator and the device's free memory
+    m.hamming_best2_device_static(q.data_ptr(), nq, t.data_ptr(), nt, index_base, got.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert (torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]) == before
+    return ref.cpu().numpy(), got.cpu().numpy()
+
+
+def test_static_scratch_matches_allocating_entry_point():
+    import torch
+    m = vsa.Matcher(device=0)
+    # first call: large enough for the two-pass (seeded) search, 2^18 + 37 rows, ragged query count
+    t1 = vsa.synth_descriptors(42, (1 << 18) + 37)
+    q1, _ = vsa.synth_queries(43, t1, 1000)
+    t1[5000:5004] = t1[10:14]                                   # equal rows: the lowest index must win in both
+    ref, got = _both(m, torch, q1, t1, 123456)
+    assert np.array_equal(ref, got)
+    assert (ref[:, 0] <= 50).sum() > 900 and ref[:, 1].min() >= 123456
+    # second call, smaller in both dimensions (one-pass search, fewer runs, fewer queries)
+    t2 = vsa.synth_descriptors(7, 3001)
+    q2, _ = vsa.synth_queries(8, t2, 77)
+    ref, got = _both(m, torch, q2, t2, 0)
+    assert np.array_equal(ref, got)
+    assert (ref[:, 0] <= 50).sum() > 60
+    # empty map: start values
+    ref, got = _both(m, torch, q2, t2[:0], 0)
+    assert np.array_equal(ref, got) and (got[:, 0] == 256).all() and (got[:, 1] == -1).all()
+    m.close()
+
+
+def test_static_scratch_rejects_oversized_requests():
+    import torch
+    m = vsa.Matcher(device=0)
+    dev = torch.device("cuda:0")
+    nq = 16384 + 128
+    q = torch.zeros((nq, 32), dtype=torch.uint8, device=dev)
+    t = torch.zeros((4096, 32), dtype=torch.uint8, device=dev)
+    out = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
+    with pytest.raises(vsa.OrbxError) as e:
+        m.hamming_best2_device_static(q.data_ptr(), nq, t.data_ptr(), 4096, 0, out.data_ptr(), None)
+    assert e.value.status == 4 and "fixed scratch" in str(e.value)
+    m.close()

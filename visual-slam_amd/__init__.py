@@ -94,6 +94,7 @@ _SIGS = {
     "orbx_compute_three_maxima": (None, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "orbx_hamming_best2": (_i, [_vp, _vp, _i, _vp, _i64, _vp]),
     "orbx_hamming_best2_device": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _vp, _vp]),
+    "orbx_hamming_best2_device_static": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _vp, _vp]),
     "orbx_best2_merge_device": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "orbx_best2_merge": (_i, [_vp, _i, _i, _vp]),
     "orbx_hamming_best2_workspace_bytes": (_i64, [_i, _i64]),
@@ -403,6 +404,10 @@ class Matcher:
 
     def hamming_best2_device(self, d_q, nq, d_t, nt, index_base, d_out, stream=None):
         _check(lib.orbx_hamming_best2_device(self.h, d_q, nq, d_t, nt, index_base, d_out, stream))
+
+    def hamming_best2_device_static(self, d_q, nq, d_t, nt, index_base, d_out, stream=None):
+        """The variant that allocates nothing (fixed device scratch)."""
+        _check(lib.orbx_hamming_best2_device_static(self.h, d_q, nq, d_t, nt, index_base, d_out, stream))
 
     def best2_merge_device(self, d_parts, n_parts, nq, d_out, stream=None):
         _check(lib.orbx_best2_merge_device(self.h, d_parts, n_parts, nq, d_out, stream))

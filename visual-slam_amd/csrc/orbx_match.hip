@@ -409,8 +409,20 @@ static size_t stereo_lds_bytes(int n_rows, int cap) { return sizeof(int32_t) * 2
 
 } // namespace
 
+// Scratch of orbx_hamming_best2_device_static: the per-run partial results (kStaticPartBytes) followed by the per-query
+// seed records of the two-pass search (kStaticSeedBytes).  Every GPU the library runs on holds its own copy until the
+// process ends.  In host code this name only stands for the symbol: the memory is reached through the per-device address
+// that hipGetSymbolAddress returns (orbx_matcher::static_scratch), never through the name.  (No `used` attribute here:
+// the host-side reference below is what makes the compiler export the symbol from the device image; with the attribute
+// it stays local there and the lookup cannot find it.)
+constexpr size_t kStaticMaxQueries = 16384;
+constexpr size_t kStaticPartBytes = 4u << 20;
+constexpr size_t kStaticSeedBytes = sizeof(orbx_best2) * kStaticMaxQueries;
+static __device__ __align__(256) unsigned char scratch[kStaticPartBytes + kStaticSeedBytes];
+
 struct orbx_matcher {
     int device = 0;
+    void* static_scratch = nullptr;                // this device's address of `scratch`, resolved at create
     hipStream_t stream = nullptr;
     void* ws = nullptr; size_t ws_bytes = 0;       // partial results of the brute-force kernel
     void* seed = nullptr; size_t seed_bytes = 0;   // its per-query result over the first rows (threshold seed of the full pass)
@@ -428,6 +440,8 @@ static int reserve(void** p, size_t* have, size_t need)
     *have = std::max<size_t>(need, 256);
     return ORBX_OK;
 }
+
+constexpr int64_t kSeedRows = 16384;             // rows of the seeding pass of large maps
 
 // Row runs of the matrix-core kernel: one per wavefront, a multiple of 32 rows, enough of them to give every SIMD two waves,
 // and as long as that allows (a lane's second-best tightens with the rows it has seen, and fewer tiles walk their keys).
@@ -457,6 +471,8 @@ int orbx_matcher_create(int device, orbx_matcher** out)
     struct Guard { orbx_matcher* p; ~Guard() { orbx_matcher_destroy(p); } } guard{m};
     HIP_CHECK(hipGetDevice(&m->device));
     HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    // the matcher's device is current here: this is that device's copy of the array
+    HIP_CHECK(hipGetSymbolAddress(&m->static_scratch, HIP_SYMBOL(scratch)));
     guard.p = nullptr;
     *out = m;
     return ORBX_OK;
@@ -480,48 +496,82 @@ int64_t orbx_hamming_best2_workspace_bytes(int nq, int64_t nt)
 {
     int rpc, nch, rpc1, nch1;
     chunking(nq, nt, rpc, nch);
-    chunking(nq, std::min<int64_t>(nt, 16384), rpc1, nch1);      // the seeding pass of large maps
+    chunking(nq, std::min<int64_t>(nt, kSeedRows), rpc1, nch1);  // the seeding pass of large maps
     return (int64_t)sizeof(Part) * std::max(nch, nch1) * nq + (int64_t)sizeof(orbx_best2) * nq;
+}
+
+// Launches of the brute-force search; parts / seed are device scratch of at least best2_part_bytes / nq records.
+static int launch_best2(const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt, int64_t index_base, orbx_best2* d_out,
+                        hipStream_t st, Part* parts, orbx_best2* seed_buf, bool seeded, int rpc, int nch, int rpc1, int nch1)
+{
+    const int qtiles = (nq + kMfmaQueries - 1) / kMfmaQueries;
+    const orbx_best2* d_seed = nullptr;
+    if (seeded) {
+        hipLaunchKernelGGL(k_best2_mfma, dim3((nch1 + 3) / 4, qtiles), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(d_q), nq,
+                           reinterpret_cast<const uint32_t*>(d_t), (long long)kSeedRows, rpc1, nch1, (const orbx_best2*)nullptr, parts);
+        hipLaunchKernelGGL(k_best2_fold, dim3((nq + 255) / 256), dim3(256), 0, st, (const Part*)parts, nch1, nq, rpc1, 0LL, seed_buf);
+        d_seed = seed_buf;
+    }
+    if (nt == 0) nch = 0;
+    if (nch > 0)
+        hipLaunchKernelGGL(k_best2_mfma, dim3((nch + 3) / 4, qtiles), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(d_q), nq,
+                           reinterpret_cast<const uint32_t*>(d_t), (long long)nt, rpc, nch, d_seed, parts);
+    hipLaunchKernelGGL(k_best2_fold, dim3((nq + 255) / 256), dim3(256), 0, st, (const Part*)parts, nch, nq, rpc, (long long)index_base, d_out);
+    HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+static int check_best2_args(const char* who, const orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
+                            int64_t index_base, const orbx_best2* d_out)
+{
+    if (!m || !d_q || !d_out || nq < 1 || nt < 0 || (nt > 0 && !d_t)) { set_error(std::string(who) + ": bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (index_base < 0 || index_base + nt > 0x7FFFFFFFLL) { set_error("global row index exceeds int32"); return ORBX_ERR_BAD_ARG; }
+    // the kernel reads queries as 16-byte and rows as 8-byte vectors
+    if (((uintptr_t)d_q & 15u) || ((uintptr_t)d_t & 7u)) { set_error(std::string(who) + ": queries must be 16-byte aligned, map rows 8-byte aligned"); return ORBX_ERR_BAD_ARG; }
+    return ORBX_OK;
 }
 
 int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt, int64_t index_base,
                               orbx_best2* d_out, void* stream)
 {
-    if (!m || !d_q || !d_out || nq < 1 || nt < 0 || (nt > 0 && !d_t)) { set_error("orbx_hamming_best2_device: bad argument"); return ORBX_ERR_BAD_ARG; }
-    if (index_base + nt > 0x7FFFFFFFLL) { set_error("global row index exceeds int32"); return ORBX_ERR_BAD_ARG; }
-    // the kernel reads queries as 16-byte and rows as 8-byte vectors
-    if (((uintptr_t)d_q & 15u) || ((uintptr_t)d_t & 7u)) { set_error("orbx_hamming_best2_device: queries must be 16-byte aligned, map rows 8-byte aligned"); return ORBX_ERR_BAD_ARG; }
+    int rc = check_best2_args("orbx_hamming_best2_device", m, d_q, nq, d_t, nt, index_base, d_out);
+    if (rc) return rc;
     HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = (hipStream_t)stream;
-    int rpc, nch;
+    int rpc, nch, rpc1 = 0, nch1 = 0;
     chunking(nq, nt, rpc, nch);
     // Large maps: a first pass over the first kSeedRows rows gives every query a second-best distance that no row of the final
     // answer exceeds; seeded with it, the full pass walks the keys of few tiles instead of warming every row run up from 256.
-    constexpr int64_t kSeedRows = 16384;
     const bool seeded = nt >= 16 * kSeedRows;
-    int rpc1 = 0, nch1 = 0;
     if (seeded) chunking(nq, kSeedRows, rpc1, nch1);
-    int rc = reserve(&m->ws, &m->ws_bytes, sizeof(Part) * (size_t)std::max(nch, nch1) * nq);
+    if ((rc = reserve(&m->ws, &m->ws_bytes, sizeof(Part) * (size_t)std::max(nch, nch1) * nq))) return rc;
+    if (seeded && (rc = reserve(&m->seed, &m->seed_bytes, sizeof(orbx_best2) * (size_t)nq))) return rc;
+    return launch_best2(d_q, nq, d_t, nt, index_base, d_out, (hipStream_t)stream, reinterpret_cast<Part*>(m->ws),
+                        reinterpret_cast<orbx_best2*>(m->seed), seeded, rpc, nch, rpc1, nch1);
+}
+
+// The same search for callers that must not allocate (HIP graph capture, serving loops): the partial results and the seed
+// records live in this device's copy of `scratch`, reached through the address resolved at orbx_matcher_create.  Nothing
+// in the scratch has to start at zero: every record the fold kernels read is written first by the search launch in front
+// of them on the same stream.
+int orbx_hamming_best2_device_static(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt, int64_t index_base,
+                                     orbx_best2* d_out, void* stream)
+{
+    int rc = check_best2_args("orbx_hamming_best2_device_static", m, d_q, nq, d_t, nt, index_base, d_out);
     if (rc) return rc;
-    const int qtiles = (nq + kMfmaQueries - 1) / kMfmaQueries;
-    const orbx_best2* d_seed = nullptr;
-    if (seeded) {
-        if ((rc = reserve(&m->seed, &m->seed_bytes, sizeof(orbx_best2) * (size_t)nq))) return rc;
-        hipLaunchKernelGGL(k_best2_mfma, dim3((nch1 + 3) / 4, qtiles), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(d_q), nq,
-                           reinterpret_cast<const uint32_t*>(d_t), (long long)kSeedRows, rpc1, nch1, (const orbx_best2*)nullptr,
-                           reinterpret_cast<Part*>(m->ws));
-        hipLaunchKernelGGL(k_best2_fold, dim3((nq + 255) / 256), dim3(256), 0, st, reinterpret_cast<const Part*>(m->ws), nch1, nq, rpc1,
-                           0LL, reinterpret_cast<orbx_best2*>(m->seed));
-        d_seed = reinterpret_cast<const orbx_best2*>(m->seed);
+    if (!m->static_scratch) { set_error("orbx_hamming_best2_device_static: the device scratch was not resolved at create"); return ORBX_ERR_HIP; }
+    int rpc, nch, rpc1 = 0, nch1 = 0;
+    chunking(nq, nt, rpc, nch);
+    const bool seeded = nt >= 16 * kSeedRows;
+    if (seeded) chunking(nq, kSeedRows, rpc1, nch1);
+    if ((size_t)nq > kStaticMaxQueries || sizeof(Part) * (size_t)std::max(nch, nch1) * (size_t)nq > kStaticPartBytes) {
+        set_error("orbx_hamming_best2_device_static: needs more than the fixed scratch (at most 16384 queries and 4 MiB of partial "
+                  "results, see orbx_hamming_best2_workspace_bytes); use orbx_hamming_best2_device");
+        return ORBX_ERR_CAPACITY;
     }
-    if (nt == 0) nch = 0;
-    if (nch > 0)
-        hipLaunchKernelGGL(k_best2_mfma, dim3((nch + 3) / 4, qtiles), dim3(kBlock), 0, st, reinterpret_cast<const uint32_t*>(d_q), nq,
-                           reinterpret_cast<const uint32_t*>(d_t), (long long)nt, rpc, nch, d_seed, reinterpret_cast<Part*>(m->ws));
-    hipLaunchKernelGGL(k_best2_fold, dim3((nq + 255) / 256), dim3(256), 0, st, reinterpret_cast<const Part*>(m->ws), nch, nq, rpc,
-                       (long long)index_base, d_out);
-    HIP_CHECK(hipGetLastError());
-    return ORBX_OK;
+    HIP_CHECK(hipSetDevice(m->device));
+    unsigned char* base = static_cast<unsigned char*>(m->static_scratch);
+    return launch_best2(d_q, nq, d_t, nt, index_base, d_out, (hipStream_t)stream, reinterpret_cast<Part*>(base),
+                        reinterpret_cast<orbx_best2*>(base + kStaticPartBytes), seeded, rpc, nch, rpc1, nch1);
 }
 
 int orbx_best2_merge_device(orbx_matcher* m, const orbx_best2* d_parts, int n_parts, int nq, orbx_best2* d_out, void* stream)
