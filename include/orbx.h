@@ -28,7 +28,7 @@ extern "C" {
 typedef enum orbx_status {
     ORBX_OK = 0,
     ORBX_ERR_BAD_ARG = 1,
-    ORBX_ERR_UNSUPPORTED_GEOMETRY = 2, /* the reference divides by zero for this image size (src/ORBextractor.cc:542-544, 783-786) or the size exceeds the packed-coordinate range */
+    ORBX_ERR_UNSUPPORTED_GEOMETRY = 2, /* the reference is undefined for this image size (width/height < 0.5: empty root list, src/ORBextractor.cc:542-568; a level smaller than its own 16-pixel borders) or the size exceeds the packed-coordinate range.  Levels too small for one FAST cell (:783-786) are accepted: they yield no keypoints */
     ORBX_ERR_HIP = 3,
     ORBX_ERR_CAPACITY = 4,             /* caller's output capacity too small */
     ORBX_ERR_NO_DEVICE = 5

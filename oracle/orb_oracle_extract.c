@@ -701,11 +701,13 @@ static int compute_keypoints_octree(orc_extractor* ex)
         const float width = (float)(maxBorderX - minBorderX);
         const float height = (float)(maxBorderY - minBorderY);
         if (!(width > 0) || !(height > 0)) return 2;
-        const int nCols = (int)(width / W);
-        const int nRows = (int)(height / W);
-        if (nCols <= 0 || nRows <= 0) return 2; /* reference: integer division by zero at :785-786 */
-        const int wCell = (int)ceilf(width / nCols);
-        const int hCell = (int)ceilf(height / nRows);
+        int nCols = (int)(width / W);
+        int nRows = (int)(height / W);
+        /* :785-786 with nCols or nRows == 0: width / nCols is a float division (inf, no trap); the cell loops below then
+         * run zero times and the level hands DistributeOctTree an empty list.  wCell / hCell are never used in that case. */
+        if (nCols <= 0 || nRows <= 0) nCols = nRows = 0;
+        const int wCell = nCols ? (int)ceilf(width / nCols) : 0;
+        const int hCell = nRows ? (int)ceilf(height / nRows) : 0;
 
         ptrdiff_t ps = L->w + 2 * EDGE_THRESHOLD;
         const uint8_t* roi = L->padded + EDGE_THRESHOLD * ps + EDGE_THRESHOLD;
@@ -746,7 +748,9 @@ static int compute_keypoints_octree(orc_extractor* ex)
         const int N = ex->mnFeaturesPerLevel[level];
         int cap = L->ncand + 8;
         int32_t* sel = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
-        int nsel = orc_distribute_octree(L->cx, L->cy, L->cs, L->ncand, minBorderX, maxBorderX, minBorderY, maxBorderY, N, sel, cap);
+        /* with no candidates the reference's DistributeOctTree returns an empty vector whatever nIni is (:565-569 never run) */
+        int nsel = L->ncand == 0 && nCols == 0 ? 0
+                 : orc_distribute_octree(L->cx, L->cy, L->cs, L->ncand, minBorderX, maxBorderX, minBorderY, maxBorderY, N, sel, cap);
         if (nsel < 0) { free(sel); return 2; }
         L->kp_cap = nsel > 0 ? nsel : 1;
         L->kps = (orc_keypoint*)malloc(sizeof(orc_keypoint) * (size_t)L->kp_cap);

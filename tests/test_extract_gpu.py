@@ -22,6 +22,8 @@ CONFIGS = [
     (480, 640, 1000, 8, 1.2, 20, 7, 10),     # portrait
     (1600, 1200, 3000, 8, 1.2, 20, 7, 11),   # between 1 and 2 Mpixel: 512-thread quadtree workgroups
     (1241, 376, 2000, 8, 1.2, 12, 12, 12),   # KITTI04-12-like thresholds (ini == min), cells above 38 pixels in one level
+    (160, 120, 500, 8, 1.2, 20, 7, 13),      # levels 4..7 are under 62 px high: no FAST cell fits, they yield no keypoints
+    (320, 180, 500, 8, 1.2, 20, 7, 14),      # same for levels 6 and 7
 ]
 
 
@@ -133,8 +135,34 @@ def test_unsupported_geometry_is_an_error(vsa):
         vsa.Extractor(vsa.make_params(500, 1.2, 8), 100, 300, device=0)   # W/H < 0.5 -> nIni == 0 in the reference
     assert e.value.status == 2
     with pytest.raises(vsa.OrbxError) as e:
-        vsa.Extractor(vsa.make_params(500, 1.2, 8), 200, 150, device=0)   # top level narrower than 62 px
+        vsa.Extractor(vsa.make_params(500, 1.2, 8), 100, 80, device=0)    # top level (28x22) smaller than its own 16-px borders
     assert e.value.status == 2
+
+
+def test_levels_without_cells_yield_nothing(vsa, oracle):
+    """A level whose detection area is under 30 px on a side has nCols or nRows == 0 (src/ORBextractor.cc:783-786): the
+    reference's cell loops run zero times and the level contributes no keypoints, while the other levels work normally."""
+    w, h = 160, 120
+    img = vsa.synth_frame(6, w, h)
+    ex = vsa.Extractor(vsa.make_params(500, 1.2, 8), w, h, max_batch=2, device=0)
+    kps, desc = ex.extract(img)
+    okps, odesc = oracle.Extractor(oracle.make_params(500, 1.2, 8)).extract(img)
+    assert len(kps) == len(okps) > 100 and np.array_equal(desc, odesc)
+    assert np.array_equal(kps, okps.astype(vsa.KEYPOINT_DTYPE))
+    per_level = np.bincount(kps["octave"], minlength=8)
+    assert np.all(per_level[:4] > 0) and np.all(per_level[4:] == 0)
+    for l in range(4, 8):
+        assert len(ex.debug_candidates(0, l)) == 0 and len(ex.debug_level_keypoints(0, l)) == 0
+        assert np.array_equal(ex.pyramid_level(0, l), oracle_level(oracle, img, l))
+    bk, bd, bc = ex.extract_batch(np.stack([img, img]))
+    assert bc[0] == bc[1] == len(okps) and np.array_equal(bd[1][:bc[1]], odesc)
+    ex.close()
+
+
+def oracle_level(oracle, img, l):
+    oex = oracle.Extractor(oracle.make_params(500, 1.2, 8))
+    oex.extract(img)
+    return oex.level_padded(l)
 
 
 def test_octree_standalone_random(vsa, oracle):

@@ -42,6 +42,11 @@ def test_level_sizes_and_capacity(vsa):
     assert e.value.status == 2
     with pytest.raises(vsa.OrbxError):
         vsa.keypoint_capacity(vsa.make_params(nlevels=0), 640, 480)
+    # levels too small to hold a FAST cell are accepted (they yield nothing); levels smaller than their own borders are not
+    assert vsa.keypoint_capacity(vsa.make_params(500, 1.2, 8), 160, 120) >= 500
+    with pytest.raises(vsa.OrbxError) as e:
+        vsa.keypoint_capacity(vsa.make_params(500, 1.2, 8), 100, 80)
+    assert e.value.status == 2
 
 
 def test_errors_without_gpu_are_loud(vsa):

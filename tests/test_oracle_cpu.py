@@ -215,6 +215,25 @@ def test_extract_is_deterministic_and_bounded(oracle, vsa):
     assert len(kc) == 0
 
 
+def test_levels_too_small_for_a_cell_yield_nothing(oracle, vsa):
+    """src/ORBextractor.cc:783-786 with nCols or nRows == 0: `width/nCols` is a float division (inf, no trap), the cell loops
+    run zero times and DistributeOctTree gets an empty list -- the level has no keypoints, the others are unaffected.
+    160x120 with 8 levels: levels 4..7 are 77x58 and smaller (detection area under 30 rows).  Only a level smaller than
+    its own 16-pixel borders is rejected."""
+    img = vsa.synth_frame(6, 160, 120)
+    k8, d8 = oracle.Extractor(oracle.make_params(500, 1.2, 8)).extract(img)
+    per_level = np.bincount(k8["octave"], minlength=8)
+    assert np.all(per_level[:4] > 0) and np.all(per_level[4:] == 0)
+    # the four populated levels behave exactly as in a 4-level pyramid given the same per-level quotas
+    ex = oracle.Extractor(oracle.make_params(500, 1.2, 8))
+    ex.extract(img)
+    for l in range(4, 8):
+        assert len(ex.level_candidates(l)[0]) == 0 and len(ex.level_keypoints(l)) == 0
+        assert ex.level_padded(l).shape[0] == vsa.level_size(vsa.make_params(500, 1.2, 8), 160, 120, l)[1] + 38
+    with pytest.raises(Exception):
+        oracle.Extractor(oracle.make_params(500, 1.2, 8)).extract(vsa.synth_frame(6, 100, 80))
+
+
 def test_distinctive_descriptor_known_answers(oracle):
     """src/MapPoint.cc:513-547 by hand: descriptors with 0, 1, 2, 3 and 40 set bits.  Rows of the distance matrix sorted:
     [0,1,2,3,40] [0,1,1,2,39] [0,1,1,2,38] [0,1,2,3,37] [0,37,38,39,40]; medians (element 2): 2, 1, 1, 2, 38 -> index 1

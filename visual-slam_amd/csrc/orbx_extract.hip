@@ -743,6 +743,11 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
     if ((tid & 63) == 0) atomicAdd(&s_nk, part);
     __syncthreads();
     const int nk = s_nk;
+    // no candidates (always so for a level too small to hold a FAST cell): DistributeOctTree returns nothing, whatever nIni is
+    if (nk == 0) {
+        if (tid == 0) lvlcnt[frame * nlevels + level] = 0;
+        return;
+    }
     // two copies of the same code, one per home of the key arrays: with the address space known at compile time the LDS
     // copy gets DS instructions (a pointer chosen at run time would make every key access a FLAT one)
     int n;

@@ -148,19 +148,23 @@ int build_geometry(const orbx_params& p, int width, int height, Geometry& g)
         if (!(fw > 0) || !(fh > 0)) { set_error("pyramid level smaller than the 32-pixel border"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
         L.nCols = (int)(fw / W);               // :783-786
         L.nRows = (int)(fh / W);
-        if (L.nCols <= 0 || L.nRows <= 0) {
-            set_error("pyramid level narrower than 62 pixels: the reference divides by zero (src/ORBextractor.cc:785-786)");
-            return ORBX_ERR_UNSUPPORTED_GEOMETRY;
+        // A level whose detection area is under 30 pixels wide or high has nCols or nRows == 0: the reference's float
+        // divisions (:785-786) give inf without trapping, its cell loops run zero times and DistributeOctTree returns
+        // nothing for the empty candidate list, so the level simply yields no keypoints while its quota stays unused.
+        const bool no_cells = L.nCols <= 0 || L.nRows <= 0;
+        if (no_cells) { L.nCols = L.nRows = 0; L.wCell = L.hCell = 0; }
+        else {
+            L.wCell = (int)std::ceil(fw / L.nCols);
+            L.hCell = (int)std::ceil(fh / L.nRows);
         }
-        L.wCell = (int)std::ceil(fw / L.nCols);
-        L.hCell = (int)std::ceil(fh / L.nRows);
         if (L.maxBorderX - kMinBorder - 4 >= 4096 || L.maxBorderY - kMinBorder - 4 >= 4096) {
             set_error("level larger than 4128 pixels: packed 12-bit candidate coordinates overflow");
             return ORBX_ERR_UNSUPPORTED_GEOMETRY;
         }
-        // DistributeOctTree roots, :542-544
+        // DistributeOctTree roots, :542-544 (never consulted for a level without cells: no key is ever assigned to a root)
         L.nIni = (int)std::round((float)(L.maxBorderX - kMinBorder) / (L.maxBorderY - kMinBorder));
-        if (L.nIni <= 0) { set_error("width/height < 0.5: the reference divides by zero (src/ORBextractor.cc:542-544)"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+        if (no_cells) L.nIni = std::min(std::max(L.nIni, 1), kMaxRoots);
+        if (L.nIni <= 0) { set_error("width/height < 0.5: the reference indexes an empty root list (src/ORBextractor.cc:542-568)"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
         if (L.nIni > kMaxRoots) { set_error("width/height > 64 not supported"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
         L.hX = (float)(L.maxBorderX - kMinBorder) / L.nIni;
 
