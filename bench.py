@@ -41,9 +41,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--contexts", type=int, default=8,
+    ap.add_argument("--contexts", type=int, default=4,
                     help="extractor contexts per GPU, each on its own HIP stream with batch/contexts frames "
-                         "(the reference runs two extractors concurrently for stereo, src/Frame.cc:78-81)")
+                         "(the reference runs two extractors concurrently for stereo, src/Frame.cc:78-81); a process has "
+                         "four hardware queues, so more than four streams share queues and serialise")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
@@ -476,7 +477,7 @@ def worker(a):
         ksteps = max(2, min(a.steps, 20))
         configs.append(leg_stereo(cx, vsa, np, ksteps, 2))
         torch.cuda.empty_cache()
-        configs.append(leg_config_extract(cx, vsa, np, "kitti_1241x376", 1241, 376, 2000, 8, a.kitti_frames, True, 8, 128,
+        configs.append(leg_config_extract(cx, vsa, np, "kitti_1241x376", 1241, 376, 2000, 8, a.kitti_frames, True, 4, 128,
                                           max(2, min(a.steps, 5)), 1,
                                           f"one batch of {a.kitti_frames} HBM-resident 1241x376 frames, nFeatures=2000, split over the ranks "
                                           "(BASELINE configs[2]; one step = the whole batch)"))

@@ -130,6 +130,27 @@ def test_fallback_threshold_cells(vsa, oracle):
     ex.close()
 
 
+def test_dense_cells(vsa, oracle):
+    """Cells with more pretest survivors than the kernel's survivor list holds (noise at a low threshold: most pixels of
+    a cell are corners) take the path that scores round by round and walks all pixels: same candidates, same output.
+    Also a wide-cell geometry (cells above 38 pixels) and a frame that is half noise, half flat."""
+    rng = np.random.default_rng(77)
+    for w, h, ini, mn in ((320, 240, 5, 2), (400, 300, 3, 3), (1241, 376, 4, 1)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        img[:, w // 2:] = np.where(rng.random((h, w - w // 2)) < 0.5, img[:, w // 2:], 128) if w == 400 else img[:, w // 2:]
+        ex = vsa.Extractor(vsa.make_params(600, 1.2, 4, ini, mn), w, h, max_batch=1, device=0)
+        oex = oracle.Extractor(oracle.make_params(600, 1.2, 4, ini, mn))
+        kps, desc = ex.extract(img)
+        okps, odesc = oex.extract(img)
+        for l in range(4):
+            gx, gy, gs = vsa.unpack_keys(ex.debug_candidates(0, l))
+            ox, oy, os_ = oex.level_candidates(l)
+            assert len(gx) == len(ox) and np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gs, os_), (w, h, l)
+        assert len(oex.level_candidates(0)[0]) > 20 * (w // 30) * (h // 30)       # tens of maxima per cell: far beyond the usual
+        assert np.array_equal(kps, okps.astype(vsa.KEYPOINT_DTYPE)) and np.array_equal(desc, odesc)
+        ex.close()
+
+
 def test_unsupported_geometry_is_an_error(vsa):
     with pytest.raises(vsa.OrbxError) as e:
         vsa.Extractor(vsa.make_params(500, 1.2, 8), 100, 300, device=0)   # W/H < 0.5 -> nIni == 0 in the reference

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liborbx.so")
+LIB_PATH = os.environ.get("ORBX_LIB_PATH") or os.path.join(_HERE, "csrc", "liborbx.so")   # the override lets a tool time two builds side by side
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                            ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

@@ -408,6 +408,8 @@ __global__ __launch_bounds__(256) void k_borders(uint8_t* __restrict__ pyr, unsi
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxCellDim = 60;      // cells are at most 59 wide (wCell = ceil(width / floor(width/30)))
 constexpr int kSmallCellDim = 38;    // the usual case (wCell 30..38): smaller LDS tiles, more resident wavefronts
+constexpr int kSmallQueue = 480;     // survivor list of a usual cell (a third of its pixels): eight workgroups per CU
+constexpr int kBigQueue = 1024;
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
@@ -493,40 +495,64 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// One wavefront per cell, four cells per workgroup; no workgroup barrier anywhere.
-//   tile load -> per threshold attempt { [pass 1: packed pretest of 256 pixels per round, survivors queued ->
-//   pass 2: exact score of the queued survivors whenever the queue fills, and at the end] -> pass 3: strict local
-//   maxima among the corners } -> lane r owns row r of the cell: raster-ordered emission.
-// TS/TR: tile row stride (bytes) and rows, SS/SR: score tile stride and rows.
-
-template <int TS, int TR, int SS, int SR>
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
-                                                    const DevLevel* __restrict__ lv, const CellRec* __restrict__ cells,
-                                                    uint32_t* __restrict__ cand, int cand_total,
-                                                    uint16_t* __restrict__ cellcnt, int ncells, const int32_t* __restrict__ list,
-                                                    int nlist, int iniTh, int minTh, int n_frames)
+// divisions by the number of four-pixel groups in a cell row, as tables (the divisor is uniform: scalar loads)
+struct GroupsPerRow { int rows[16]; int magic[16]; };
+constexpr GroupsPerRow make_groups_per_row()
 {
+    GroupsPerRow t{};
+    for (int g = 1; g < 16; ++g) { t.rows[g] = 64 / g; t.magic[g] = (65536 + g - 1) / g; }
+    return t;
+}
+__constant__ const GroupsPerRow kGroupsPerRow = make_groups_per_row();
+
+// What one wavefront needs to know about its cell, in launch order (read with scalar loads: one round trip before the
+// tile can be fetched, where cell list -> cell record -> level record took three).
+struct FastCell {
+    uint32_t src;        // byte offset of the cell sub-image's first pixel inside a frame's pyramid
+    uint32_t stride;     // bytes per row of the level
+    uint16_t cw, ch;     // detection area
+    uint16_t offx, offy; // j*wCell, i*hCell
+    uint32_t out;        // first candidate slot of the cell inside a frame's slot array
+    uint32_t cap;        // slots reserved
+    uint32_t cell;       // index into the per-frame count array
+    uint32_t pad;
+};
+
+// One wavefront per cell, four cells per workgroup; no workgroup barrier anywhere.
+//   tile load -> per threshold attempt { pass 1: packed pretest of 256 pixels per round, survivors kept as bits ->
+//   queued -> pass 2: exact score of the queued survivors -> pass 3: strict local maxima among the corners }
+//   -> every maximum finds its own rank in raster order and writes its key.
+// TS/TR: tile row stride (bytes) and rows, SS/SR: score tile stride and rows, MR: rows of the maxima masks,
+// QCAP: entries of the survivor / corner list.  The LDS per workgroup decides how many wavefronts a CU holds, and the
+// kernel lives on that (its phases wait on LDS and memory round trips): the list is sized for the usual cell, not for
+// the worst one.  A cell with more survivors than the list holds takes the dense path: its rounds are queued and
+// scored one at a time, no corner list is kept, and passes 3 and the emission walk all pixels of the cell instead.
+template <int TS, int TR, int SS, int SR, int MR, int QCAP>
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
+                                                    const FastCell* __restrict__ fcells, int nlist,
+                                                    uint32_t* __restrict__ cand, int cand_total,
+                                                    uint16_t* __restrict__ cellcnt, int ncells,
+                                                    int iniTh, int minTh, int n_frames)
+{
+    static_assert(QCAP >= 256 && QCAP % 8 == 0 && (SR * SS) % 16 == 0 && MR <= 64, "list holds at least one round");
     __shared__ __align__(16) uint8_t s_tile[4][TR * TS];
     __shared__ __align__(16) uint8_t s_score[4][SR * SS];
-    __shared__ unsigned long long s_mask[4][64];
-    // one list per cell: the scored pixels (corners at the lower threshold) found so far, then the pretest survivors
-    // waiting for their score; together never more than the pixels of the cell
-    constexpr int QCAP = ((TR - 6) * (TR - 6) + 7) & ~7;
+    __shared__ unsigned long long s_mask[4][MR];
     __shared__ uint16_t s_queue[4][QCAP];
+    __shared__ uint16_t s_base[4][MR];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything derived from it stays scalar
     int frame; uint32_t blk;
     if (!frame_chunk(blockIdx.x, (nlist + 3) >> 2, n_frames, frame, blk)) return;
     if ((int)blk * 4 + wave >= nlist) return;
-    const int cell = list[(int)blk * 4 + wave];          // the cells this launch's tile size fits
-    const CellRec c = cells[cell];
-    const DevLevel& L = lv[c.level];
-    const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + L.roi + (long long)c.y0 * L.stride + c.x0;
+    const FastCell c = fcells[(int)blk * 4 + wave];
+    const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + c.src;
     uint8_t* tile = s_tile[wave];
     uint8_t* score = s_score[wave];
     unsigned long long* rowmask = s_mask[wave];
     uint16_t* queue = s_queue[wave];
+    uint16_t* rowbase = s_base[wave];
     const int cw = c.cw, ch = c.ch;
     const int tw = cw + 6, th = ch + 6;
     {
@@ -535,28 +561,62 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         const int r0 = lane / LPR, j = lane - r0 * LPR;
         if (lane < LPR * RPI && 16 * j < tw)
             for (int r = r0; r < th; r += RPI) {
-                const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(src + ((uint32_t)r * (uint32_t)L.stride + 16u * (uint32_t)j));
+                const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(src + ((uint32_t)r * c.stride + 16u * (uint32_t)j));
                 *reinterpret_cast<uint4*>(tile + r * TS + 16 * j) = make_uint4(t.x, t.y, t.z, t.w);
             }
     }
     // pretest lanes: groups of four pixels, gpr per row (<= 15), as many whole rows per round as 64 lanes hold
     const int gpr = (cw + 3) >> 2;
-    const int rows_per_round = 64 / gpr;
-    const int lrow = (lane * ((65536 + gpr - 1) / gpr)) >> 16;      // lane / gpr (exact for lane < 64, gpr <= 15)
+    const int rows_per_round = kGroupsPerRow.rows[gpr];              // 64 / gpr
+    const int lrow = (lane * kGroupsPerRow.magic[gpr]) >> 16;        // lane / gpr (exact for lane < 64, gpr <= 15)
     const int g = lane - lrow * gpr;
     const int x = 4 * g;
     // survivor mask layout: pixel 0, 2 of the lane's four in bits 0, 1 and pixel 1, 3 in bits 16, 17
     const int npx = lrow < rows_per_round ? min(cw - x, 4) : 0;            // pixels of the lane inside the cell
     const uint32_t colmask = (npx > 0 ? 1u : 0u) | (npx > 1 ? 1u << 16 : 0u) | (npx > 2 ? 2u : 0u) | (npx > 3 ? 2u << 16 : 0u);
+    const int qbase = lrow * 64 + x;                                       // list entry of the lane's first pixel in round 0
+
+    // exact scores of queue[0..n): corners (score >= T) go to the score tile and, when LIST, to the front of the queue
+    // (a scored entry is written at or below the slot its lane just read, so no waiting entry is overwritten)
+    auto score_queued = [&](int n, int T, bool list) -> int {
+        int kept = 0;
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            const int e = e0 + lane;
+            bool keep = false;
+            int i = 0;
+            if (e < n) {
+                i = queue[e];
+                const int yy = i >> 6, xx = i & 63;
+                const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
+                keep = sc >= T;
+                if (keep) score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
+            }
+            if (list) {
+                const unsigned long long m = __ballot(keep);
+                if (keep) queue[kept + lanes_below(m)] = (uint16_t)i;
+                kept += __popcll(m);
+            }
+        }
+        return kept;
+    };
+    // pixel (xx, yy) of the cell is a corner with a score above its eight neighbours inside the cell
+    auto strict_max = [&](int yy, int xx) -> bool {
+        const uint8_t* sp = &score[(yy + 1) * SS + xx + 1];
+        const int sc = sp[0];
+        return sc > sp[-1] && sc > sp[1] && sc > sp[-SS - 1] && sc > sp[-SS] && sc > sp[-SS + 1] &&
+               sc > sp[SS - 1] && sc > sp[SS] && sc > sp[SS + 1];
+    };
 
     // cv::FAST(cell, T, nonmax) at T = iniThFAST; only if that returns nothing, at T = minThFAST (:808-815).  Pixels
     // scoring below T play no part at threshold T (a kept pixel beats them anyway), so each attempt scores only
     // its own corners; nearly every cell is done after the first.
     unsigned long long mask = 0;
+    int nsq = 0;                                                     // corners of the last attempt: queue[0..nsq)
+    bool dense = false;                                              // ... unless the list could not hold the survivors
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int T = max(attempt == 0 ? iniTh : minTh, 1);          // score >= T  <=>  corner at threshold T (T >= 1)
-        for (int i = lane; i < (ch + 2) * (SS / 16); i += 64) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
-        rowmask[lane] = 0;
+        for (int i = lane; i < ((ch + 2) * SS + 15) >> 4; i += 64) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
+        if (lane < MR) rowmask[lane] = 0;
         wave_sync();
         const s16x2 thr1 = {(short)(T + 1), (short)(T + 1)};
         // pass 1: every lane keeps the survivors of its four pixels per round as a nibble of its own bit set (round r in bits
@@ -584,70 +644,77 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                 mybits |= (Bits)((pm & 3u) | ((pm >> 14) & 0xCu)) << (4 * round);
             }
         }
-        // the survivors of the whole cell go to the queue in one step: a prefix sum of the lanes' counts, then every lane
-        // writes its own (the order inside the queue does not matter)
-        int nq, nsq = 0;
-        {
-            const int mine = __popcll((unsigned long long)mybits);
+        // the survivors in `bits` go to the queue in one step: a prefix sum of the lanes' counts, then every lane
+        // writes its own (the order inside the queue does not matter); returns how many there are
+        auto enqueue = [&](Bits bits) -> int {
+            const int mine = __popcll((unsigned long long)bits);
             const int incl = ot_wave_scan_incl(mine);
-            nq = __builtin_amdgcn_readlane(incl, 63);
             int off = incl - mine;
-            const int base = lrow * 64 + x;
-            while (mybits) {
-                const int bpos = sizeof(Bits) == 4 ? __ffs((int)mybits) - 1 : __ffsll((long long)mybits) - 1;
-                mybits &= mybits - 1;
+            while (bits) {
+                const int bpos = sizeof(Bits) == 4 ? __ffs((int)bits) - 1 : __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
                 const int k = bpos & 3;
-                queue[off++] = (uint16_t)(base + (bpos >> 2) * (rows_per_round * 64) + (((k & 1) << 1) | (k >> 1)));
+                queue[off++] = (uint16_t)(qbase + (bpos >> 2) * (rows_per_round * 64) + (((k & 1) << 1) | (k >> 1)));
             }
-        }
-        // pass 2: exact score of the queued survivors; corners go to the score tile and the scored list
-        // (a scored entry is written at or below the slot its lane just read, so no waiting entry is overwritten)
-        wave_sync();
-        for (int e0 = 0; e0 < nq; e0 += 64) {
-            const int e = e0 + lane;
-            bool keep = false;
-            int i = 0;
-            if (e < nq) {
-                i = queue[e];
+            return __builtin_amdgcn_readlane(incl, 63);
+        };
+        const int nq = wave_sum_i32(__popcll((unsigned long long)mybits));
+        dense = nq > QCAP;
+        if (!dense) {
+            enqueue(mybits);
+            wave_sync();
+            // pass 2: exact score of the queued survivors
+            nsq = score_queued(nq, T, true);
+            wave_sync();
+            // pass 3: strict local maxima inside the cell among the corners, one lane per corner; row masks of the maxima
+            for (int e = lane; e < nsq; e += 64) {
+                const int i = queue[e];
                 const int yy = i >> 6, xx = i & 63;
-                const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
-                keep = sc >= T;
-                if (keep) score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
+                if (strict_max(yy, xx)) atomicOr(&rowmask[yy], 1ull << xx);
             }
-            const unsigned long long m = __ballot(keep);
-            if (keep) queue[nsq + lanes_below(m)] = (uint16_t)i;
-            nsq += __popcll(m);
+        } else {
+            // more survivors than the list holds: one round (at most 256 of them) at a time, scores only
+            for (int r = 0; r < round; ++r) {
+                const int n = enqueue(mybits & ((Bits)0xF << (4 * r)));
+                wave_sync();
+                score_queued(n, T, false);
+                wave_sync();
+            }
+            for (int i = lane; i < cw * ch; i += 64) {
+                const int yy = i / cw, xx = i - yy * cw;
+                if (score[(yy + 1) * SS + xx + 1] && strict_max(yy, xx)) atomicOr(&rowmask[yy], 1ull << xx);
+            }
         }
         wave_sync();
-        // pass 3: strict local maxima inside the cell among the corners, one lane per corner; row masks of the maxima
-        for (int e = lane; e < nsq; e += 64) {
-            const int i = queue[e];
-            const int yy = i >> 6, xx = i & 63;
-            const uint8_t* sp = &score[(yy + 1) * SS + xx + 1];
-            const int sc = sp[0];
-            const bool mx = sc > sp[-1] && sc > sp[1] &&
-                            sc > sp[-SS - 1] && sc > sp[-SS] && sc > sp[-SS + 1] &&
-                            sc > sp[SS - 1] && sc > sp[SS] && sc > sp[SS + 1];
-            if (mx) atomicOr(&rowmask[yy], 1ull << xx);
-        }
-        wave_sync();
-        mask = rowmask[lane];                                         // lane r owns row r (rows >= ch are empty)
+        mask = lane < MR ? rowmask[lane] : 0ull;                      // lane r owns row r (rows >= ch are empty)
         if (__any(mask != 0ull) || max(minTh, 1) >= T) break;         // a second attempt at a threshold not below T finds nothing new
         wave_sync();
     }
+    // raster-ordered emission: row r's maxima start at the number of maxima in the rows above it (lane r owns row r for
+    // the prefix sum); then every maximum finds its own rank -- its row's start plus the maxima to its left in the
+    // row -- and writes its key: one pass over the corner list instead of one round per maximum of the fullest row
     const int cnt = __popcll(mask);
     const int inc = ot_wave_scan_incl(cnt);
     const int total = __builtin_amdgcn_readlane(inc, 63);
-    int pos = inc - cnt;
-    uint32_t* out = cand + (unsigned long long)frame * cand_total + L.cand_offset + c.slot;
-    while (mask) {
-        const int xx = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const int sc = score[(lane + 1) * SS + xx + 1];
-        if (pos < c.cap) out[pos] = ((uint32_t)(xx + 3 + c.offx) << 20) | ((uint32_t)(lane + 3 + c.offy) << 8) | (uint32_t)sc;
-        ++pos;
+    uint32_t* out = cand + (unsigned long long)frame * cand_total + c.out;
+    if (total) {
+        if (lane < MR) rowbase[lane] = (uint16_t)(inc - cnt);
+        wave_sync();
+        const uint32_t keybase = ((uint32_t)(3 + c.offx) << 20) | ((uint32_t)(3 + c.offy) << 8);
+        auto emit = [&](int yy, int xx) {
+            const unsigned long long m = rowmask[yy];
+            if ((m >> xx) & 1ull) {
+                const int pos = rowbase[yy] + __popcll(m & ((1ull << xx) - 1ull));
+                const int sc = score[(yy + 1) * SS + xx + 1];
+                if (pos < (int)c.cap) out[pos] = keybase + ((uint32_t)xx << 20) + ((uint32_t)yy << 8) + (uint32_t)sc;
+            }
+        };
+        if (!dense)
+            for (int e = lane; e < nsq; e += 64) { const int i = queue[e]; emit(i >> 6, i & 63); }
+        else
+            for (int i = lane; i < cw * ch; i += 64) { const int yy = i / cw; emit(yy, i - yy * cw); }
     }
-    if (lane == 0) cellcnt[(unsigned long long)frame * ncells + cell] = (uint16_t)min(total, c.cap);
+    if (lane == 0) cellcnt[(unsigned long long)frame * ncells + c.cell] = (uint16_t)min(total, (int)c.cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1358,7 +1425,7 @@ struct orbx_extractor {
     std::vector<DevLevel> hlv;
     DevLevel* d_lv = nullptr;
     CellRec* d_cells = nullptr;
-    int32_t* d_cell_list = nullptr;   // cell indices: the n_small cells of at most kSmallCellDim pixels, then the n_big others
+    FastCell* d_fast_cells = nullptr;  // per launch slot of k_fast_cells: the n_small cells of at most kSmallCellDim pixels, then the n_big others
     int n_small = 0, n_big = 0;
     ResizeX* d_rx = nullptr;
     ResizeY* d_ry = nullptr;
@@ -1509,8 +1576,19 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
             (std::max(geo.cells[i].cw, geo.cells[i].ch) <= kSmallCellDim ? small : big).push_back((int32_t)i);
         ex->n_small = (int)small.size(); ex->n_big = (int)big.size();
         small.insert(small.end(), big.begin(), big.end());
-        HIP_CHECK(hipMalloc(&ex->d_cell_list, sizeof(int32_t) * std::max<size_t>(small.size(), 1)));
-        if (!small.empty()) HIP_CHECK(hipMemcpy(ex->d_cell_list, small.data(), sizeof(int32_t) * small.size(), hipMemcpyHostToDevice));
+        std::vector<FastCell> fc(std::max<size_t>(small.size(), 1));
+        for (size_t i = 0; i < small.size(); ++i) {
+            const CellRec& c = geo.cells[small[i]];
+            const LevelGeom& g = geo.lv[c.level];
+            const size_t src = g.roi + (size_t)c.y0 * g.stride + c.x0;
+            if (src + (size_t)(c.ch + 6) * g.stride > 0xFFFFFFFFull) { set_error("pyramid of one frame beyond 4 GiB"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+            FastCell& f = fc[i];
+            f.src = (uint32_t)src; f.stride = (uint32_t)g.stride;
+            f.cw = (uint16_t)c.cw; f.ch = (uint16_t)c.ch; f.offx = (uint16_t)c.offx; f.offy = (uint16_t)c.offy;
+            f.out = (uint32_t)(g.cand_offset + c.slot); f.cap = (uint32_t)c.cap; f.cell = (uint32_t)small[i]; f.pad = 0;
+        }
+        HIP_CHECK(hipMalloc(&ex->d_fast_cells, sizeof(FastCell) * fc.size()));
+        HIP_CHECK(hipMemcpy(ex->d_fast_cells, fc.data(), sizeof(FastCell) * fc.size(), hipMemcpyHostToDevice));
     }
     if (!geo.rx.empty()) HIP_CHECK(hipMemcpy(ex->d_rx, geo.rx.data(), sizeof(ResizeX) * geo.rx.size(), hipMemcpyHostToDevice));
     if (!geo.ry.empty()) HIP_CHECK(hipMemcpy(ex->d_ry, geo.ry.data(), sizeof(ResizeY) * geo.ry.size(), hipMemcpyHostToDevice));
@@ -1541,7 +1619,7 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     if (!ex) return;
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-    void* ptrs[] = {ex->d_pts, ex->d_octmem, ex->d_lv, ex->d_cells, ex->d_cell_list, ex->d_rx, ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
+    void* ptrs[] = {ex->d_pts, ex->d_octmem, ex->d_lv, ex->d_cells, ex->d_fast_cells, ex->d_rx, ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
                     ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     void* hptrs[] = {ex->h_pts, ex->h_img, ex->h_okp, ex->h_odesc, ex->h_ocount, ex->h_level};
@@ -1610,13 +1688,13 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
         // ones (a level whose border-to-border span is just under a multiple of 30) get their own launch
         const int nc = (int)G.cells.size();
         if (ex->n_small)
-            hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 48, kSmallCellDim + 2>), dim3(frame_chunk_grid((ex->n_small + 3) / 4, B)),
-                               dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, cand, G.cand_total, cellcnt, nc,
-                               ex->d_cell_list, ex->n_small, ex->params.ini_th_fast, ex->params.min_th_fast, B);
+            hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 40, kSmallCellDim + 2, 40, kSmallQueue>), dim3(frame_chunk_grid((ex->n_small + 3) / 4, B)),
+                               dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_fast_cells, ex->n_small, cand, G.cand_total, cellcnt, nc,
+                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
         if (ex->n_big)
-            hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2>), dim3(frame_chunk_grid((ex->n_big + 3) / 4, B)),
-                               dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, ex->d_cells, cand, G.cand_total, cellcnt, nc,
-                               ex->d_cell_list + ex->n_small, ex->n_big, ex->params.ini_th_fast, ex->params.min_th_fast, B);
+            hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2, 64, kBigQueue>), dim3(frame_chunk_grid((ex->n_big + 3) / 4, B)),
+                               dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_fast_cells + ex->n_small, ex->n_big, cand, G.cand_total, cellcnt, nc,
+                               ex->params.ini_th_fast, ex->params.min_th_fast, B);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
     {
