@@ -237,6 +237,12 @@ __device__ __forceinline__ uint2 resize_window(const uint8_t* p, uint32_t shift)
     return make_uint2(__builtin_amdgcn_alignbyte(t.y, t.x, shift), __builtin_amdgcn_alignbyte(t.z, t.y, shift));
 }
 
+// bits 32..47 of the product of two 24-bit values (v_mul_hi_u32_u24)
+__device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b)
+{
+    return (uint32_t)(((unsigned long long)(a & 0xFFFFFFu) * (unsigned long long)(b & 0xFFFFFFu)) >> 32);
+}
+
 template <bool kSharedRows>
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel S, DevLevel D,
                                                 const ResizeY* __restrict__ ryt, const ResizeRowBlock* __restrict__ rrb,
@@ -293,19 +299,23 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
             b0[r] = (uint32_t)(int)ey[r].b0; b1[r] = (uint32_t)(int)ey[r].b1;
         }
     }
+    // OpenCV's vertical pass, ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2, with each product as one
+    // 24-bit high multiply: (b << 12) * (H & ~15) = b * (H >> 4) * 2^16, whose bits 32.. are the shifted product
+    // (b <= 2^11 after the host's check, H < 2^19: both factors fit 24 bits).  The four result bytes are packed by
+    // byte selects, which also drop everything above bit 7 as the cast to uchar does.
     uint32_t out[kResizeRows];
 #pragma unroll
     for (int r = 0; r < kResizeRows; ++r) {
-        uint32_t v = 0;
+        const uint32_t c0 = b0[r] << 12, c1 = b1[r] << 12;
+        uint32_t b[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const us16x2 w = __builtin_bit_cast(us16x2, wt[k]);
             const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r0[r].y, r0[r].x, sel[k])), w, 0u, false);
             const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r1[r].y, r1[r].x, sel[k])), w, 0u, false);
-            const uint32_t b = (((__umul24(b0[r], h0 >> 4) >> 16) + (__umul24(b1[r], h1 >> 4) >> 16) + 2u) >> 2) & 0xFFu;
-            v |= b << (8 * k);
+            b[k] = (mul_hi_u24(c0, h0 & ~15u) + mul_hi_u24(c1, h1 & ~15u) + 2u) >> 2;
         }
-        out[r] = v;
+        out[r] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(b[3], b[2], 0x0c0c0400u), __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u), 0x05040100u);
     }
 #pragma unroll
     for (int r = 0; r < kResizeRows; ++r) {
@@ -644,11 +654,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                 mybits |= (Bits)((pm & 3u) | ((pm >> 14) & 0xCu)) << (4 * round);
             }
         }
-        // the survivors in `bits` go to the queue in one step: a prefix sum of the lanes' counts, then every lane
-        // writes its own (the order inside the queue does not matter); returns how many there are
-        auto enqueue = [&](Bits bits) -> int {
-            const int mine = __popcll((unsigned long long)bits);
-            const int incl = ot_wave_scan_incl(mine);
+        // the survivors in `bits` go to the queue in one step: a prefix sum of the lanes' counts (incl, of which `mine`
+        // are the lane's own), then every lane writes its own (the order inside the queue does not matter)
+        auto enqueue = [&](Bits bits, int incl, int mine) {
             int off = incl - mine;
             while (bits) {
                 const int bpos = sizeof(Bits) == 4 ? __ffs((int)bits) - 1 : __ffsll((long long)bits) - 1;
@@ -656,12 +664,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                 const int k = bpos & 3;
                 queue[off++] = (uint16_t)(qbase + (bpos >> 2) * (rows_per_round * 64) + (((k & 1) << 1) | (k >> 1)));
             }
-            return __builtin_amdgcn_readlane(incl, 63);
         };
-        const int nq = wave_sum_i32(__popcll((unsigned long long)mybits));
+        const int mine = __popcll((unsigned long long)mybits);
+        const int incl = ot_wave_scan_incl(mine);
+        const int nq = __builtin_amdgcn_readlane(incl, 63);
         dense = nq > QCAP;
         if (!dense) {
-            enqueue(mybits);
+            enqueue(mybits, incl, mine);
             wave_sync();
             // pass 2: exact score of the queued survivors
             nsq = score_queued(nq, T, true);
@@ -675,7 +684,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         } else {
             // more survivors than the list holds: one round (at most 256 of them) at a time, scores only
             for (int r = 0; r < round; ++r) {
-                const int n = enqueue(mybits & ((Bits)0xF << (4 * r)));
+                const Bits rb = mybits & ((Bits)0xF << (4 * r));
+                const int rmine = __popcll((unsigned long long)rb);
+                const int rincl = ot_wave_scan_incl(rmine);
+                const int n = __builtin_amdgcn_readlane(rincl, 63);
+                enqueue(rb, rincl, rmine);
                 wave_sync();
                 score_queued(n, T, false);
                 wave_sync();
