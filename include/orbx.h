@@ -55,6 +55,7 @@ typedef struct orbx_params {
     int32_t ini_th_fast;
     int32_t min_th_fast;
     int32_t blur_rounding; /* 0: generic C++ column pass, (sum+32768)>>16.  1: x86 SIMD column pass of OpenCV <= 3.4.0 (exact value rounded half-to-even for x < (w & ~3), generic for the last w%4 columns) */
+    int32_t trig_mode;     /* cos / sin of the keypoint angle in computeOrbDescriptor (src/ORBextractor.cc:111-112, which calls the float overloads, i.e. glibc cosf / sinf).  0: the correctly rounded (float)cos((double)theta).  1: glibc >= 2.28 cosf / sinf as x86-64 CPUs with FMA and AVX2 run it (the contracted __cosf_fma / __sinf_fma), bit for bit.  2: the same routine evaluated without fused multiply-adds (x86-64 without FMA) */
 } orbx_params;
 
 /* Binary layout of cv::KeyPoint: pt.x, pt.y, size, angle, response, octave, class_id (28 bytes). */
@@ -142,6 +143,10 @@ int orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, uint32_
 /* GaussianBlur(7x7, sigma 2) of one level of the last batch (the workingMat of src/ORBextractor.cc:1084-1085),
  * w x h pixels copied to dst (host). */
 int orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride);
+/* Test tap: cos and sin as orbx_params.trig_mode defines them, of angle * (float)(pi/180) (src/ORBextractor.cc:111-112)
+ * for the `count` float angles whose bit patterns start at first_bits; d_cos / d_sin are device arrays of `count`
+ * floats; runs on `stream`.  Lets a test walk every float angle in [0, 360) against the host's cosf / sinf. */
+int orbx_debug_trig_range(int trig_mode, uint32_t first_bits, uint32_t count, float* d_cos, float* d_sin, void* stream);
 
 /* DistributeOctTree on its own (src/ORBextractor.cc:538-762): host arrays in, device kernel, host out.
  * keys packed as above; out receives the selected keys in list order. */

@@ -32,7 +32,17 @@ typedef struct orc_params {
     int32_t ini_th_fast;
     int32_t min_th_fast;
     int32_t blur_rounding; /* 0 = (sum+32768)>>16 everywhere; 1 = x86 SIMD column pass (ties to even for x < w&~3) */
+    int32_t trig_mode;     /* cos/sin in computeOrbDescriptor: 0 = (float)cos((double)t); 1 = restatement of glibc cosf/sinf as
+                              its x86-64 FMA build evaluates it; 2 = the same without fused multiply-adds; 3 = this host's libm
+                              cosf/sinf called directly (the function src/ORBextractor.cc:112 calls) */
 } orc_params;
+
+/* cos and sin of theta under trig_mode (see orc_params) */
+void orc_trig(int trig_mode, float theta, float* cos_out, float* sin_out);
+/* the same for angle * (float)(pi/180), angle = the floats with bit patterns first_bits .. first_bits + count - 1 */
+void orc_trig_range(int trig_mode, uint32_t first_bits, uint32_t count, float* cos_out, float* sin_out);
+/* number of those angles for which modes a and b differ in cos or sin (bitwise) */
+uint64_t orc_trig_count_differences(int mode_a, int mode_b, uint32_t first_bits, uint32_t count);
 
 /* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
 typedef struct orc_keypoint {
@@ -47,6 +57,7 @@ typedef struct orc_extractor orc_extractor;
 /* ---- primitives (OpenCV semantics) ---- */
 int   orc_cv_round(double v);
 float orc_fast_atan2(float y, float x);
+void orc_fast_atan2_array(const float* y, const float* x, int n, float* out);
 void  orc_resize_linear_u8(const uint8_t* src, int sw, int sh, ptrdiff_t sstride,
                            uint8_t* dst, int dw, int dh, ptrdiff_t dstride);
 /* fills the `pad`-pixel frame around the w x h ROI at roi (buffer stride `stride`) by REFLECT_101 of the ROI */

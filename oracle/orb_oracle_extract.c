@@ -71,6 +71,11 @@ float orc_fast_atan2(float y, float x)
     return a;
 }
 
+void orc_fast_atan2_array(const float* y, const float* x, int n, float* out)
+{
+    for (int i = 0; i < n; ++i) out[i] = orc_fast_atan2(y[i], x[i]);
+}
+
 /* BORDER_REFLECT_101 index map (core/copy.cpp borderInterpolate). */
 static int reflect101(int p, int len)
 {
@@ -663,15 +668,96 @@ static float ic_angle(const uint8_t* center, ptrdiff_t step, const int* u_max)
     return orc_fast_atan2((float)m_01, (float)m_10);
 }
 
-/* computeOrbDescriptor, src/ORBextractor.cc:106-146.  cos/sin: the reference calls the float
- * overloads (glibc cosf/sinf); the canonical definition used here and on the device is the
- * correctly rounded value (float)cos((double)angle), which glibc 2.35 cosf/sinf reproduces for
- * all but ~0.04%/0.09% of the float angles in [0,360) deg. */
-static void orb_descriptor(const orc_keypoint* kpt, const uint8_t* img, ptrdiff_t step, uint8_t* desc)
+/* glibc's sinf / cosf since 2.28 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h; constants of
+ * __sincosf_table), restated for |y| < 120: one reduction by pi/2, then a double-precision polynomial.  use_fma = 1
+ * evaluates `a + b * c` fused wherever the library's x86-64 FMA build (__sinf_fma / __cosf_fma, picked by its ifunc
+ * on CPUs with FMA and AVX2) does; use_fma = 0 rounds every operation (the SSE2 build).  tests/test_oracle_cpu.py
+ * walks every float angle in [0, 360) and finds this host's libm equal to one of the two. */
+static double gl_mad(int use_fma, double a, double b, double c) { return use_fma ? fma(a, b, c) : a * b + c; }   /* built with -ffp-contract=off: a * b + c rounds twice */
+static float gl_poly(int use_fma, double x, double x2, int negate, int cosine)
+{
+    const double sg = negate ? -1.0 : 1.0;     /* __sincosf_table[1]: c0..c4 negated, s1..s3 unchanged */
+    if (!cosine) {
+        const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+        double x3 = x * x2;
+        double t = gl_mad(use_fma, x2, s3, s2);
+        double x7 = x3 * x2;
+        double u = gl_mad(use_fma, x3, s1, x);
+        return (float)gl_mad(use_fma, x7, t, u);
+    }
+    const double c0 = sg * 0x1p0, c1 = sg * -0x1.ffffffd0c621cp-2, c2 = sg * 0x1.55553e1068f19p-5,
+                 c3 = sg * -0x1.6c087e89a359dp-10, c4 = sg * 0x1.99343027bf8c3p-16;
+    double x4 = x2 * x2;
+    double t2 = gl_mad(use_fma, x2, c4, c3);
+    double t1 = gl_mad(use_fma, x2, c1, c0);
+    double x6 = x4 * x2;
+    double c = gl_mad(use_fma, x4, c2, t1);
+    return (float)gl_mad(use_fma, x6, t2, c);
+}
+static void gl_sincosf(int use_fma, float y, float* sn, float* cs)
+{
+    uint32_t bits; memcpy(&bits, &y, 4);
+    const uint32_t top12 = (bits >> 20) & 0x7FFu;
+    double x = y;
+    if (top12 < 0x3F4u) {                       /* abstop12(y) < abstop12(pio4) */
+        if (top12 < 0x398u) { *sn = y; *cs = 1.0f; return; }
+        double x2 = x * x;
+        *sn = gl_poly(use_fma, x, x2, 0, 0);
+        *cs = gl_poly(use_fma, x, x2, 0, 1);
+        return;
+    }
+    double r = x * 0x1.45F306DC9C883p+23;                 /* reduce_fast, !TOINT_INTRINSICS */
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    const double hpi = 0x1.921FB54442D18p0;
+    x = use_fma ? fma(-(double)n, hpi, x) : x - n * hpi;
+    double x2 = x * x;
+    static const double sign[4] = {1.0, -1.0, -1.0, 1.0};
+    double xs = x * sign[n & 3];
+    *sn = gl_poly(use_fma, xs, x2, n & 2, n & 1);
+    *cs = gl_poly(use_fma, xs, x2, n & 2, !(n & 1));
+}
+
+void orc_trig(int trig_mode, float theta, float* cos_out, float* sin_out)
+{
+    if (trig_mode == 1 || trig_mode == 2) gl_sincosf(trig_mode == 1, theta, sin_out, cos_out);
+    else if (trig_mode == 3) { *cos_out = cosf(theta); *sin_out = sinf(theta); }     /* what src/ORBextractor.cc:112 calls */
+    else { *cos_out = (float)cos((double)theta); *sin_out = (float)sin((double)theta); }
+}
+
+static const float k_factorPI = (float)(3.1415926535897932384626433832795 / 180.f);   /* src/ORBextractor.cc:63 */
+
+void orc_trig_range(int trig_mode, uint32_t first_bits, uint32_t count, float* cos_out, float* sin_out)
+{
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t b = first_bits + i;
+        float angle; memcpy(&angle, &b, 4);
+        orc_trig(trig_mode, angle * k_factorPI, cos_out + i, sin_out + i);
+    }
+}
+
+uint64_t orc_trig_count_differences(int mode_a, int mode_b, uint32_t first_bits, uint32_t count)
+{
+    uint64_t n = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t b = first_bits + i;
+        float angle, ca, sa, cb, sb; memcpy(&angle, &b, 4);
+        orc_trig(mode_a, angle * k_factorPI, &ca, &sa);
+        orc_trig(mode_b, angle * k_factorPI, &cb, &sb);
+        n += memcmp(&ca, &cb, 4) != 0 || memcmp(&sa, &sb, 4) != 0;
+    }
+    return n;
+}
+
+/* computeOrbDescriptor, src/ORBextractor.cc:106-146.  cos/sin: the reference calls the float overloads (glibc
+ * cosf/sinf), trig_mode 3 here; trig_mode 1 / 2 restate that routine so that the device can follow it bit for bit;
+ * trig_mode 0, the default, is the correctly rounded value (float)cos((double)angle), which glibc 2.35 cosf/sinf
+ * reproduces for all but ~0.04%/0.09% of the float angles in [0,360) deg. */
+static void orb_descriptor(const orc_keypoint* kpt, const uint8_t* img, ptrdiff_t step, uint8_t* desc, int trig_mode)
 {
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float angle = kpt->angle * factorPI;
-    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    float a, b;
+    orc_trig(trig_mode, angle, &a, &b);
     const uint8_t* center = img + (ptrdiff_t)orc_cv_round(kpt->y) * step + orc_cv_round(kpt->x);
     const int8_t* pat = k_pattern;
 #define GET_VALUE(idx) \
@@ -801,7 +887,7 @@ int orc_extract(orc_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t s
         L->blurred = (uint8_t*)malloc((size_t)L->w * L->h);
         orc_gauss7(roi, L->w, L->h, ps, L->blurred, L->w, ex->p.blur_rounding);
         for (int k = 0; k < L->nkp; ++k)
-            orb_descriptor(&L->kps[k], L->blurred, L->w, desc + (size_t)(offset + k) * 32);
+            orb_descriptor(&L->kps[k], L->blurred, L->w, desc + (size_t)(offset + k) * 32, ex->p.trig_mode);
         float scale = ex->mvScaleFactor[level];
         for (int k = 0; k < L->nkp; ++k) {
             orc_keypoint kp = L->kps[k];

@@ -24,7 +24,7 @@ int main()
         p.nfeatures = uni(1, 9000); p.nlevels = uni(1, 14);
         const float sfs[] = {1.05f, 1.1f, 1.2f, 1.25f, 1.3f, 1.5f, 2.0f, 3.0f};
         p.scale_factor = sfs[uni(0, 7)];
-        p.ini_th_fast = uni(1, 60); p.min_th_fast = uni(1, p.ini_th_fast); p.blur_rounding = uni(0, 1);
+        p.ini_th_fast = uni(1, 60); p.min_th_fast = uni(1, p.ini_th_fast); p.blur_rounding = uni(0, 1); p.trig_mode = uni(0, 2);
         const int w = it % 50 == 0 ? uni(1, 9000) : uni(40, 2200), h = it % 50 == 1 ? uni(1, 9000) : uni(40, 1400);
         Geometry g;
         const int rc = build_geometry(p, w, h, g);

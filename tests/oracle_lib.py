@@ -16,7 +16,7 @@ BEST2_DTYPE = np.dtype([("best", "<i4"), ("best_idx", "<i4"), ("second", "<i4"),
 
 class Params(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
-                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("blur_rounding", C.c_int32)]
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("blur_rounding", C.c_int32), ("trig_mode", C.c_int32)]
 
 
 def _build_if_needed():
@@ -31,6 +31,7 @@ _vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
 _pd = C.c_ssize_t
 lib.orc_cv_round.restype = _i; lib.orc_cv_round.argtypes = [_d]
 lib.orc_fast_atan2.restype = _f; lib.orc_fast_atan2.argtypes = [_f, _f]
+lib.orc_fast_atan2_array.restype = None; lib.orc_fast_atan2_array.argtypes = [_vp, _vp, _i, _vp]
 lib.orc_resize_linear_u8.restype = None; lib.orc_resize_linear_u8.argtypes = [_vp, _i, _i, _pd, _vp, _i, _i, _pd]
 lib.orc_border101.restype = None; lib.orc_border101.argtypes = [_vp, _i, _i, _pd, _i]
 lib.orc_fast9.restype = _i; lib.orc_fast9.argtypes = [_vp, _i, _i, _pd, _i, _i, _vp, _vp, _vp, _i]
@@ -69,8 +70,8 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def make_params(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, blur_rounding=0):
-    return Params(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, blur_rounding)
+def make_params(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, blur_rounding=0, trig_mode=0):
+    return Params(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, blur_rounding, trig_mode)
 
 
 def cv_round(v):
@@ -79,6 +80,13 @@ def cv_round(v):
 
 def fast_atan2(y, x):
     return lib.orc_fast_atan2(float(y), float(x))
+
+
+def fast_atan2_array(y, x):
+    y = np.ascontiguousarray(y, np.float32); x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(len(y), np.float32)
+    lib.orc_fast_atan2_array(_ptr(y), _ptr(x), len(y), _ptr(out))
+    return out
 
 
 def resize_linear(src, dw, dh):
@@ -196,6 +204,39 @@ def distribute_octree(x, y, s, minX, maxX, minY, maxY, N):
     if n < 0:
         raise ValueError("unsupported geometry")
     return out[:n].copy()
+
+
+ANGLE_BITS_END = int(np.float32(360.0).view(np.uint32))     # float angles in [0, 360): bit patterns 0 .. this - 1
+lib.orc_trig_range.restype = None; lib.orc_trig_range.argtypes = [_i, C.c_uint32, C.c_uint32, _vp, _vp]
+lib.orc_trig_count_differences.restype = C.c_uint64; lib.orc_trig_count_differences.argtypes = [_i, _i, C.c_uint32, C.c_uint32]
+
+
+def _threads():
+    return max(1, min(16, (os.cpu_count() or 1)))
+
+
+def trig_range(mode, first_bits, count, threads=None):
+    """(cos, sin) of angle * (float)(pi/180) under trig_mode `mode` for the float angles with bit patterns
+    first_bits .. first_bits + count - 1; split over host threads (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    cs = np.empty(count, np.float32); sn = np.empty(count, np.float32)
+    step = 1 << 20
+    def run(o):
+        n = min(step, count - o)
+        lib.orc_trig_range(mode, first_bits + o, n, cs[o:].ctypes.data, sn[o:].ctypes.data)
+    with ThreadPoolExecutor(threads or _threads()) as ex:
+        list(ex.map(run, range(0, count, step)))
+    return cs, sn
+
+
+def trig_count_differences(mode_a, mode_b, first_bits=0, count=None, threads=None):
+    from concurrent.futures import ThreadPoolExecutor
+    count = ANGLE_BITS_END - first_bits if count is None else count
+    step = 1 << 22
+    def run(o):
+        return lib.orc_trig_count_differences(mode_a, mode_b, first_bits + o, min(step, count - o))
+    with ThreadPoolExecutor(threads or _threads()) as ex:
+        return sum(ex.map(run, range(0, count, step)))
 
 
 def descriptor_distance(a, b):

@@ -84,6 +84,47 @@ def test_blur_rounding_simd_mode(vsa, oracle):
     ex.close()
 
 
+def test_trig_modes_exhaustive(vsa, oracle):
+    """cos / sin of the keypoint angle (src/ORBextractor.cc:111-112) for EVERY float angle in [0, 360): the device under
+    trig_mode 1 and 2 against this host's libm cosf / sinf (oracle trig_mode 3, the function the reference calls), and
+    under trig_mode 0 against (float)cos((double)theta).  Bit for bit, no tolerance."""
+    import torch
+    chunk = 1 << 26
+    d_cos = torch.empty(chunk, dtype=torch.float32, device="cuda"); d_sin = torch.empty_like(d_cos)
+    st = torch.cuda.current_stream().cuda_stream
+    bad = {0: 0, 1: 0, 2: 0}
+    for first in range(0, oracle.ANGLE_BITS_END, chunk):
+        n = min(chunk, oracle.ANGLE_BITS_END - first)
+        want = {0: oracle.trig_range(0, first, n), 3: oracle.trig_range(3, first, n)}
+        for mode in (0, 1, 2):
+            vsa._check(vsa.lib.orbx_debug_trig_range(mode, first, n, d_cos.data_ptr(), d_sin.data_ptr(), st))
+            torch.cuda.synchronize()
+            wc, ws = want[0 if mode == 0 else 3]
+            gc, gs = d_cos[:n].cpu().numpy(), d_sin[:n].cpu().numpy()
+            bad[mode] += int(np.count_nonzero((gc.view(np.uint32) != wc.view(np.uint32)) | (gs.view(np.uint32) != ws.view(np.uint32))))
+    assert bad == {0: 0, 1: 0, 2: 0}, bad
+
+
+def test_trig_mode_glibc_end_to_end(vsa, oracle):
+    """Descriptors with cos / sin taken from libm itself (oracle trig_mode 3) equal the device's under trig_mode 1 and 2;
+    and they do differ from the default mode's somewhere in a large enough sample (the modes are not aliases)."""
+    w, h = 752, 480
+    ndiff = 0
+    for idx in range(3):
+        img = vsa.synth_frame(900 + idx, w, h)
+        okps, odesc = oracle.Extractor(oracle.make_params(2000, 1.2, 8, 12, 5, 0, 3)).extract(img, cap=2600)
+        for mode in (1, 2):
+            ex = vsa.Extractor(vsa.make_params(2000, 1.2, 8, 12, 5, 0, mode), w, h, max_batch=1, device=0)
+            kps, desc = ex.extract(img)
+            ex.close()
+            assert np.array_equal(kps, okps.astype(vsa.KEYPOINT_DTYPE)) and np.array_equal(desc, odesc), (idx, mode)
+        o0k, o0d = oracle.Extractor(oracle.make_params(2000, 1.2, 8, 12, 5, 0, 0)).extract(img, cap=2600)
+        ndiff += int(np.count_nonzero(np.any(o0d != odesc, axis=1)))
+    print("descriptors that differ between trig_mode 0 and libm:", ndiff)
+    with pytest.raises(vsa.OrbxError):
+        vsa.Extractor(vsa.make_params(trig_mode=3), w, h, device=0)
+
+
 def test_batch_matches_single(vsa, oracle):
     w, h = 640, 480
     p = vsa.make_params()

@@ -54,6 +54,112 @@ def test_cv_round_and_atan2(oracle):
         assert abs((a - np.degrees(np.arctan2(y, x))) % 360) < 0.02 or abs((a - np.degrees(np.arctan2(y, x))) % 360) > 359.98
 
 
+def test_fast_atan2_bitwise_against_numpy_float32(oracle):
+    """cv::fastAtan2 (called at src/ORBextractor.cc:102) restated a second time, in numpy float32 arithmetic (every numpy
+    float32 operation is one IEEE single-precision operation, so no fusing and no wider intermediates): the oracle's C
+    version must agree bit for bit on a million (y, x) pairs, among them integer-valued moments as IC_Angle produces."""
+    f = np.float32
+    rad2deg = f(180.0 / 3.1415926535897932384626433832795)
+    p1, p3, p5, p7 = (f(v) * rad2deg for v in (0.9997878412794807, -0.3258083974640975, 0.1555786518463281, -0.04432655554792128))
+    eps = f(2.220446049250313e-16)
+
+    def np_atan2(y, x):
+        ax, ay = np.abs(x), np.abs(y)
+        swap = ax < ay
+        num = np.where(swap, ax, ay); den = np.where(swap, ay, ax) + eps
+        c = num / den
+        c2 = c * c
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+        a = np.where(swap, f(90.0) - a, a)
+        a = np.where(x < 0, f(180.0) - a, a)
+        a = np.where(y < 0, f(360.0) - a, a)
+        return a.astype(np.float32)
+
+    rng = np.random.default_rng(11)
+    n = 1_000_000
+    y = np.concatenate([rng.integers(-2 ** 23, 2 ** 23, n // 2).astype(np.float32), rng.standard_normal(n // 2).astype(np.float32) * f(1e3)])
+    x = np.concatenate([rng.integers(-2 ** 23, 2 ** 23, n // 2).astype(np.float32), rng.standard_normal(n // 2).astype(np.float32) * f(1e3)])
+    y[:2000] = 0; x[1000:3000] = 0; y[3000:4000] = x[3000:4000]; y[4000:5000] = -x[4000:5000]
+    got = oracle.fast_atan2_array(y, x)
+    want = np_atan2(y, x)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
+    assert got.min() >= 0 and got.max() <= 360
+
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def numpy_fast9(img, threshold, nonmax=True):
+    """FAST-9 straight from its definition, independent of the oracle's min/max formulation: a pixel is a corner at
+    threshold t when 9 contiguous pixels of its 16-pixel ring are all brighter than v + t or all darker than v - t; its
+    score is the largest t at which it still is one (found by bisection on t, per pixel); with nonmax a corner stays
+    only if its score is strictly above its 8 neighbours' (non-corners and pixels outside the detection area, which
+    excludes a 3-pixel margin, count as 0).  Returns x, y, score in raster order."""
+    v = img.astype(np.int32)
+    H, W = v.shape
+    c = v[3:H - 3, 3:W - 3]
+    d = np.stack([c - v[3 + dy:H - 3 + dy, 3 + dx:W - 3 + dx] for dx, dy in RING])      # v - p_k
+
+    def corner(t):                                        # t: scalar or per-pixel array
+        dark = d > t; bright = d < -t
+        hit = np.zeros(c.shape, bool)
+        for k in range(16):
+            idx = [(k + j) % 16 for j in range(9)]
+            hit |= dark[idx].all(axis=0) | bright[idx].all(axis=0)
+        return hit
+
+    is_corner = corner(threshold)
+    lo = np.full(c.shape, threshold, np.int32)            # largest t known to fire (for corners)
+    hi = np.full(c.shape, 256, np.int32)                  # smallest t known not to
+    while np.any(hi - lo > 1):
+        mid = (lo + hi) // 2
+        f = corner(mid)
+        lo = np.where(f, mid, lo); hi = np.where(f, hi, mid)
+    score = np.where(is_corner, lo, 0)
+    if nonmax:
+        pad = np.pad(score, 1)
+        keep = is_corner.copy()
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dx or dy:
+                    keep &= score > pad[1 + dy:1 + dy + score.shape[0], 1 + dx:1 + dx + score.shape[1]]
+    else:
+        keep = is_corner
+    ys, xs = np.nonzero(keep)
+    return xs + 3, ys + 3, score[ys, xs]
+
+
+def test_fast9_against_definition(oracle, vsa):
+    """The oracle's FAST (OpenCV's arc-minimum score and rolling-row non-maximum suppression) against the definition
+    above, on noise, on the synthetic frames of the benchmarks, on low-contrast data and on narrow sub-images like the
+    extractor's cells; thresholds as the settings files use them."""
+    rng = np.random.default_rng(21)
+    images = [rng.integers(0, 256, (48, 57), dtype=np.uint8),
+              vsa.synth_frame(3, 160, 120),
+              ((vsa.synth_frame(4, 120, 90).astype(np.int32) - 128) // 5 + 128).astype(np.uint8),
+              rng.integers(100, 140, (36, 36), dtype=np.uint8),
+              np.kron(rng.integers(0, 2, (8, 9)) * 90 + 40, np.ones((6, 6))).astype(np.uint8),
+              rng.integers(0, 256, (7, 40), dtype=np.uint8),          # one detection row
+              rng.integers(0, 256, (6, 40), dtype=np.uint8)]          # too small: nothing
+    total = 0
+    for img in images:
+        for t in (7, 20, 1, 40):
+            for nonmax in (False, True):
+                gx, gy, gs = oracle.fast9(img, t, nonmax=nonmax)
+                if img.shape[0] < 7:
+                    assert len(gx) == 0
+                    continue
+                wx, wy, ws = numpy_fast9(img, t, nonmax=nonmax)
+                assert len(gx) == len(wx), (img.shape, t, nonmax, len(gx), len(wx))
+                assert np.array_equal(gx, wx) and np.array_equal(gy, wy), (img.shape, t, nonmax)
+                if nonmax:                                # without suppression cv::FAST leaves the response 0
+                    assert np.array_equal(gs, ws), (img.shape, t)
+                else:
+                    assert all(oracle.fast9_score(img, int(a), int(b), t) == int(c) for a, b, c in list(zip(wx, wy, ws))[:300])
+                total += len(gx)
+    assert total > 5000
+
+
 def test_gauss_taps_and_blur(oracle):
     assert oracle.gauss_taps().tolist() == [18, 34, 49, 55, 49, 34, 18]
     const = np.full((20, 24), 77, np.uint8)
@@ -232,6 +338,24 @@ def test_levels_too_small_for_a_cell_yield_nothing(oracle, vsa):
         assert ex.level_padded(l).shape[0] == vsa.level_size(vsa.make_params(500, 1.2, 8), 160, 120, l)[1] + 38
     with pytest.raises(Exception):
         oracle.Extractor(oracle.make_params(500, 1.2, 8)).extract(vsa.synth_frame(6, 100, 80))
+
+
+def test_glibc_trig_restatement_equals_this_hosts_libm(oracle):
+    """src/ORBextractor.cc:112 calls cos/sin on a float under `using namespace std`: glibc's cosf / sinf.  trig_mode 3 of
+    the oracle calls this host's libm; trig_modes 1 and 2 restate its algorithm (with and without the fused multiply-adds
+    of the x86-64 FMA build).  Walk EVERY float angle in [0, 360): libm equals both restatements bit for bit (the two
+    differ in double precision for about 1 % of the angles, never after rounding to float), so the device, which follows
+    the restatement, is pinned to the real callee.  The default trig_mode 0 (correctly rounded) differs from libm for
+    about 0.13 % of the angles -- counted here so the figure in the documentation stays honest."""
+    assert oracle.ANGLE_BITS_END == 0x43B40000
+    assert oracle.trig_count_differences(3, 1) == 0
+    assert oracle.trig_count_differences(3, 2) == 0
+    n0 = oracle.trig_count_differences(3, 0)
+    assert 1_000_000 < n0 < 2_000_000, n0
+    # spot values: quadrant boundaries and the small-angle branches
+    for deg, c, s in ((0.0, 1.0, 0.0), (90.0, -4.371139e-08, 1.0), (180.0, -1.0, -8.742278e-08)):
+        cs, sn = oracle.trig_range(3, int(np.float32(deg).view(np.uint32)), 1)
+        assert cs[0] == np.float32(c) and sn[0] == np.float32(s), (deg, cs[0], sn[0])
 
 
 def test_distinctive_descriptor_known_answers(oracle):

@@ -22,7 +22,7 @@ STAGES = ("pyramid", "fast", "octree", "describe")
 
 class Params(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
-                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("blur_rounding", C.c_int32)]
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("blur_rounding", C.c_int32), ("trig_mode", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -74,6 +74,7 @@ _SIGS = {
     "orbx_pyramid_levels": (_i, [_vp, _i, _vp, _vp]),
     "orbx_pyramid_level_device": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd)]),
     "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _pd]),
+    "orbx_debug_trig_range": (_i, [_i, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "orbx_search_by_projection_keyframe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, C.POINTER(_i)]),
     "orbx_project_best1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _i, _vp, _vp]),
     "orbx_search_by_sim3": (_i, [_vp] + [_vp] * 8 + [_i] + [_vp] * 8 + [_i, _f, _f, _f, _f, _vp, C.POINTER(_i)]),
@@ -143,8 +144,8 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def make_params(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, blur_rounding=0):
-    return Params(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, blur_rounding)
+def make_params(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, blur_rounding=0, trig_mode=0):
+    return Params(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, blur_rounding, trig_mode)
 
 
 def build_stamp():

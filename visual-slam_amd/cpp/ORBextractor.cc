@@ -17,7 +17,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST)
 {
     mParams.nfeatures = _nfeatures; mParams.scale_factor = _scaleFactor; mParams.nlevels = _nlevels;
-    mParams.ini_th_fast = _iniThFAST; mParams.min_th_fast = _minThFAST; mParams.blur_rounding = 0;
+    mParams.ini_th_fast = _iniThFAST; mParams.min_th_fast = _minThFAST; mParams.blur_rounding = 0; mParams.trig_mode = 0;
     mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
     mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     mnFeaturesPerLevel.resize(nlevels); umax.resize(16);
@@ -36,6 +36,11 @@ void ORBextractor::SetDevice(int device)
 void ORBextractor::SetBlurRounding(int mode)
 {
     if (mode != mParams.blur_rounding) { orbx_extractor_destroy(mpContext); mpContext = nullptr; mParams.blur_rounding = mode; }
+}
+
+void ORBextractor::SetTrigMode(int mode)
+{
+    if (mode != mParams.trig_mode) { orbx_extractor_destroy(mpContext); mpContext = nullptr; mParams.trig_mode = mode; }
 }
 
 void ORBextractor::SetInputFormat(int format)

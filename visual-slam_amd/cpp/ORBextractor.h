@@ -48,6 +48,9 @@ public:
     // grey conversion Tracking::GrabImage* does on the host (src/Tracking.cc:254-267), so that call site can drop its cvtColor.
     void SetInputFormat(int format);
     void SetBlurRounding(int mode);
+    // cos / sin of the keypoint angle (orbx_params::trig_mode): 0 correctly rounded, 1 / 2 glibc's cosf / sinf bit for bit
+    // (what src/ORBextractor.cc:112 calls on a glibc system)
+    void SetTrigMode(int mode);
     // Frame::UndistortKeyPoints (src/Frame.cc:404-434) for the keypoints of the last operator() call's image size:
     // cam = mK and mDistCoef (k3 = 0 when the settings file has none).  k1 == 0 copies, as the reference does.
     void UndistortKeyPoints(const std::vector<cv::KeyPoint>& vKeys, const orbx_camera& cam, std::vector<cv::KeyPoint>& vKeysUn);

@@ -1043,6 +1043,81 @@ __device__ __forceinline__ void sincos_0_2pi(double x, double& sn, double& cs)
     cs = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
 }
 
+// glibc's sinf / cosf (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h since 2.28: a double-precision
+// polynomial after one reduction by pi/2), for x = theta in [0, 120): what src/ORBextractor.cc:112 calls through the
+// float overloads of cos / sin.  FMA = true follows the build x86-64 CPUs with FMA and AVX2 run (the ifunc'ed
+// __sinf_fma / __cosf_fma: the compiler contracted `a + b * c` into fused multiply-adds, read off the library's code);
+// FMA = false is the same source evaluated operation by operation (the SSE2 build).  Constants: __sincosf_table.
+template <bool FMA> __device__ __forceinline__ double glibc_mad(double a, double b, double c)   // a * b + c
+{
+    return FMA ? __fma_rn(a, b, c) : __dadd_rn(__dmul_rn(a, b), c);
+}
+template <bool FMA> __device__ __forceinline__ float glibc_sincos_poly(double x, double x2, bool negate, bool cosine)
+{
+    const double sg = negate ? -1.0 : 1.0;                     // __sincosf_table[1] holds c0..c4 negated
+    if (!cosine) {
+        const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+        const double x3 = __dmul_rn(x, x2);
+        const double t = glibc_mad<FMA>(x2, s3, s2);           // s1' = s2 + x2 * s3
+        const double x7 = __dmul_rn(x3, x2);
+        const double u = glibc_mad<FMA>(x3, s1, x);            // s = x + x3 * s1
+        return __double2float_rn(glibc_mad<FMA>(x7, t, u));    // s + x7 * s1'
+    }
+    const double c0 = sg * 0x1p0, c1 = sg * -0x1.ffffffd0c621cp-2, c2 = sg * 0x1.55553e1068f19p-5,
+                 c3 = sg * -0x1.6c087e89a359dp-10, c4 = sg * 0x1.99343027bf8c3p-16;
+    const double x4 = __dmul_rn(x2, x2);
+    const double t2 = glibc_mad<FMA>(x2, c4, c3);              // c2' = c3 + x2 * c4
+    const double t1 = glibc_mad<FMA>(x2, c1, c0);              // c1' = c0 + x2 * c1
+    const double x6 = __dmul_rn(x4, x2);
+    const double c = glibc_mad<FMA>(x4, c2, t1);               // c = c1' + x4 * c2
+    return __double2float_rn(glibc_mad<FMA>(x6, t2, c));       // c + x6 * c2'
+}
+template <bool FMA> __device__ __forceinline__ void glibc_sincosf(float y, float& sn, float& cs)
+{
+    const uint32_t top12 = (__float_as_uint(y) >> 20) & 0x7FFu;
+    double x = (double)y;
+    if (top12 < 0x3F4u) {                                      // abstop12(y) < abstop12(pi/4)
+        if (top12 < 0x398u) { sn = y; cs = 1.0f; return; }     // |y| < 2^-12
+        const double x2 = __dmul_rn(x, x);
+        sn = glibc_sincos_poly<FMA>(x, x2, false, false);
+        cs = glibc_sincos_poly<FMA>(x, x2, false, true);
+        return;
+    }
+    // reduce_fast without round-to-int instructions: n = round(x * 2/pi) through the 2^24-scaled constant
+    const double r = __dmul_rn(x, 0x1.45F306DC9C883p+23);
+    const int n = ((int)r + 0x800000) >> 24;
+    const double hpi = 0x1.921FB54442D18p0;
+    x = FMA ? __fma_rn(-(double)n, hpi, x) : __dsub_rn(x, __dmul_rn((double)n, hpi));
+    const double x2 = __dmul_rn(x, x);
+    const double xs = __dmul_rn(x, (n + 1) & 2 ? -1.0 : 1.0);  // sign[n & 3] = {1, -1, -1, 1}
+    const bool neg = n & 2;
+    sn = glibc_sincos_poly<FMA>(xs, x2, neg, n & 1);           // sinf: sinf_poly(x * s, x2, p, n)
+    cs = glibc_sincos_poly<FMA>(xs, x2, neg, !(n & 1));        // cosf: sinf_poly(x * s, x2, p, n ^ 1)
+}
+
+// cos and sin of theta as orbx_params.trig_mode defines them
+__device__ __forceinline__ void trig_by_mode(int mode, float theta, float& a, float& b)
+{
+    if (mode == 1) glibc_sincosf<true>(theta, b, a);
+    else if (mode == 2) glibc_sincosf<false>(theta, b, a);
+    else {
+        double sd, cd;
+        sincos_0_2pi((double)theta, sd, cd);
+        a = (float)cd; b = (float)sd;
+    }
+}
+
+// cos / sin of angle * (float)(pi / 180) for the float angles whose bit patterns are first .. first + count - 1
+__global__ __launch_bounds__(256) void k_trig_range(int mode, uint32_t first, uint32_t count, float* __restrict__ cs, float* __restrict__ sn)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
+    float a, b;
+    trig_by_mode(mode, __fmul_rn(__uint_as_float(first + i), factorPI), a, b);
+    cs[i] = a; sn[i] = b;
+}
+
 // Byte weights of the intensity-centroid sums for the eight dwords of a disc row |v| read from column u = -16:
 // wu = u + 16 inside the disc, wm = 1 inside the disc, 0 outside.
 struct IcTable { uint32_t wu[16][8]; uint32_t wm[16][8]; };
@@ -1085,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
                                                   const uint32_t* __restrict__ lvlkp, int kp_total,
                                                   const int32_t* __restrict__ lvlcnt,
                                                   orbx_keypoint* __restrict__ okp, uint8_t* __restrict__ odesc,
-                                                  int32_t* __restrict__ ocount, int cap_per_frame, int n_frames)
+                                                  int32_t* __restrict__ ocount, int cap_per_frame, int n_frames, int trig_mode)
 {
     __shared__ __align__(16) uint4 s_win[4][kBlurW * kWinChunks + 1];
 
@@ -1206,9 +1281,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     const float my_angle = fast_atan2_deg((float)my01, (float)my10);
     // computeOrbDescriptor (src/ORBextractor.cc:107-146)
     constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.0); // (float)(CV_PI/180.f)
-    double sd, cd;
-    sincos_0_2pi((double)__fmul_rn(my_angle, factorPI), sd, cd);
-    const float my_a = (float)cd, my_b = (float)sd;
+    float my_a, my_b;
+    trig_by_mode(trig_mode, __fmul_rn(my_angle, factorPI), my_a, my_b);
 
     auto stage = [&](int q, const Window& f) __attribute__((always_inline)) {      // window registers -> LDS
         if (jlevel[q] < 0) return;
@@ -1733,7 +1807,7 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
             hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels, bpl, B);
         dim3 grid(frame_chunk_grid((G.kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), B));
         hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels,
-                           lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B);
+                           lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B, ex->params.trig_mode);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
     HIP_CHECK(hipGetLastError());
@@ -2092,6 +2166,16 @@ int orbx_stereo_refine(orbx_extractor* left, orbx_extractor* right, const orbx_k
     } while (0);
     cleanup();
     return rc;
+}
+
+int orbx_debug_trig_range(int trig_mode, uint32_t first_bits, uint32_t count, float* d_cos, float* d_sin, void* stream)
+{
+    if (trig_mode < 0 || trig_mode > 2 || (count && (!d_cos || !d_sin))) { set_error("orbx_debug_trig_range: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (count > (1u << 30)) { set_error("orbx_debug_trig_range: at most 2^30 angles per call"); return ORBX_ERR_BAD_ARG; }
+    if (!count) return ORBX_OK;
+    hipLaunchKernelGGL(k_trig_range, dim3((count + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, trig_mode, first_bits, count, d_cos, d_sin);
+    HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
 }
 
 int orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride)

@@ -26,6 +26,10 @@ int build_scale_tables(const orbx_params& p, ScaleTables& t)
         set_error("orbx_params: need 1 <= nlevels <= 32, nfeatures >= 0, scale_factor > 1");
         return ORBX_ERR_BAD_ARG;
     }
+    if (p.trig_mode < 0 || p.trig_mode > 2 || p.blur_rounding < 0 || p.blur_rounding > 1) {
+        set_error("orbx_params: blur_rounding is 0 or 1, trig_mode 0, 1 or 2");
+        return ORBX_ERR_BAD_ARG;
+    }
     const double scaleFactor = p.scale_factor; // the member is a double (include/ORBextractor.h:223)
     t.nlevels = p.nlevels;
     t.scale[0] = 1.0f;
