@@ -88,7 +88,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
 {
     if (_image.empty())
         return;
-    const cv::Mat& image = _image;
+    const cv::Mat image = _image.getMat();
     const int channels = mnFormat == ORBX_INPUT_GRAY ? 1 : (mnFormat <= ORBX_INPUT_BGR ? 3 : 4);
 #ifdef ORBX_WITH_OPENCV
     if (image.type() != CV_8UC(channels)) throw std::runtime_error("ORBextractor: image type does not match the input format");
@@ -108,8 +108,9 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (n == 0)
         _descriptors.release();
     else {
-        _descriptors.create(n, 32, CV_8U);
-        std::memcpy(_descriptors.ptr(), desc.ptr(), (size_t)n * 32);
+        _descriptors.create(n, 32, CV_8U);                       // src/ORBextractor.cc:1067-1068
+        cv::Mat out = _descriptors.getMat();
+        for (int r = 0; r < n; ++r) std::memcpy(out.ptr(r), desc.ptr(r), 32);
     }
     _keypoints.clear();
     _keypoints.reserve(n);

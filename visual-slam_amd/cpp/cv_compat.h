@@ -75,8 +75,28 @@ private:
     std::shared_ptr<uint8_t> owner_;
 };
 
-typedef const Mat& InputArray;
-typedef Mat& OutputArray;
+// The proxy types of OpenCV's signatures, with the part of their interface the drop-in classes use and nothing else:
+// like the real cv::_InputArray / cv::_OutputArray they are NOT matrices, so code that compiles against these also
+// compiles against the real headers (getMat() to reach the matrix, create() / release() to size an output).
+class _InputArray {
+public:
+    _InputArray(const Mat& m) : m_(&m) {}
+    Mat getMat() const { return *m_; }
+    bool empty() const { return m_->empty(); }
+private:
+    const Mat* m_;
+};
+class _OutputArray {
+public:
+    _OutputArray(Mat& m) : m_(&m) {}
+    void create(int r, int c, int type) const { m_->create(r, c, type); }
+    void release() const { m_->release(); }
+    Mat getMat() const { return *m_; }
+private:
+    Mat* m_;
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
 
 } // namespace cv
 #endif
