@@ -228,23 +228,27 @@ int orbx_search_for_initialization(orbx_matcher* m,
  * (src/ORBmatcher.cc:68-125).  Query i = one visible map point: projection (qu,qv), search radius
  * qr = r*scale[level] (:69), right-image projection qur (:93), predicted level, descriptor.
  * claimed[n2]: -1 free, >=0 taken (stands for F.mvpMapPoints[idx] with observations, :87-89); a match
- * stores the query index (:123). */
+ * stores the query index (:123).  q_transient (may be null): 1 marks a query whose map point has no observations
+ * (the temporal points stereo / RGB-D tracking creates, src/Tracking.cc UpdateLastFrame): the reference's test
+ * `F.mvpMapPoints[idx]->Observations()>0` then leaves the feature free for later queries, which may overwrite it;
+ * such a match is stored as -2 - query (still negative, still free). */
 int orbx_search_by_projection_mappoints(orbx_matcher* m,
                                         const float* qu, const float* qv, const float* qr, const float* qur,
                                         const int32_t* qlevel, const uint8_t* qdesc, int nq,
                                         const orbx_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
                                         float minX, float maxX, float minY, float maxY,
-                                        float nnratio, int32_t* claimed, int* nmatches);
+                                        float nnratio, const uint8_t* q_transient, int32_t* claimed, int* nmatches);
 
 /* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (src/ORBmatcher.cc:1381-1470) and the
  * KeyFrame form (:1531-1598): best-1 within th_dist (TH_HIGH=100 or ORBdist), rotation histogram.
- * mode 0: levels octave-1..octave+1, 1: forward (>= octave), 2: backward (0..octave). */
+ * mode 0: levels octave-1..octave+1, 1: forward (>= octave), 2: backward (0..octave).  q_transient as above
+ * (:1406-1408 is the same test); the key-frame form blocks on any map point (:1544-1545): pass null. */
 int orbx_search_by_projection_lastframe(orbx_matcher* m,
                                         const float* qu, const float* qv, const float* qradius, const float* qur,
                                         const int32_t* qoctave, const float* qangle, const uint8_t* qdesc, int nq,
                                         const orbx_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
                                         float minX, float maxX, float minY, float maxY,
-                                        int mode, int th_dist, int check_ori, int32_t* claimed, int* nmatches);
+                                        int mode, int th_dist, int check_ori, const uint8_t* q_transient, int32_t* claimed, int* nmatches);
 
 /* ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>& vpMatched, th),
  * candidate loop and acceptance (src/ORBmatcher.cc:362-401).  Query i = one projected map point that passed the

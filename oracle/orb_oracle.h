@@ -116,7 +116,9 @@ int   orc_search_by_projection_mappoints(const float* qu, const float* qv, const
                                          const int32_t* qlevel, const uint8_t* qdesc, int nq,
                                          const orc_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
                                          float minX, float maxX, float minY, float maxY,
-                                         float nnratio, int32_t* claimed /* n2: -1 free, else query idx */);
+                                         float nnratio, const uint8_t* q_transient /* may be null; 1: the query's map point has no
+                                         observations, so its match (stored as -2 - query) leaves the feature free, :87-89 */,
+                                         int32_t* claimed /* n2: -1 free, else query idx */);
 
 /* SearchByProjection(Frame, LastFrame) inner part, src/ORBmatcher.cc:1381-1470: best-1, TH_HIGH, rot-hist.
  * mode: 0 = both neighbours (level-1..level+1), 1 = forward (>= level), 2 = backward (0..level) */
@@ -124,7 +126,8 @@ int   orc_search_by_projection_lastframe(const float* qu, const float* qv, const
                                          const int32_t* qoctave, const float* qangle, const uint8_t* qdesc, int nq,
                                          const orc_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
                                          float minX, float maxX, float minY, float maxY,
-                                         int mode, int th_dist, int check_ori, int32_t* claimed);
+                                         int mode, int th_dist, int check_ori, const uint8_t* q_transient /* as above, :1406-1408 */,
+                                         int32_t* claimed);
 
 /* Frame::ComputeStereoMatches Hamming part, src/Frame.cc:466-549. best_dist/best_idx per left keypoint
  * (best_dist = 100 and idx = 0 when nothing beat the start value; -1 marks "skipped" queries). */

@@ -223,7 +223,7 @@ int orc_search_by_projection_mappoints(const float* qu, const float* qv, const f
                                        const int32_t* qlevel, const uint8_t* qdesc, int nq,
                                        const orc_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
                                        float minX, float maxX, float minY, float maxY,
-                                       float nnratio, int32_t* claimed)
+                                       float nnratio, const uint8_t* q_transient, int32_t* claimed)
 {
     int nmatches = 0;
     orc_frame_grid* g = orc_grid_create(k2, n2, minX, maxX, minY, maxY);
@@ -246,7 +246,7 @@ int orc_search_by_projection_mappoints(const float* qu, const float* qv, const f
         }
         if (bestDist <= TH_HIGH) {
             if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
-            claimed[bestIdx] = i;
+            claimed[bestIdx] = (q_transient && q_transient[i]) ? -2 - i : i;   /* F.mvpMapPoints[bestIdx]=pMP; it blocks later queries only if pMP->Observations()>0 */
             nmatches++;
         }
     }
@@ -261,7 +261,7 @@ int orc_search_by_projection_lastframe(const float* qu, const float* qv, const f
                                        const int32_t* qoctave, const float* qangle, const uint8_t* qdesc, int nq,
                                        const orc_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
                                        float minX, float maxX, float minY, float maxY,
-                                       int mode, int th_dist, int check_ori, int32_t* claimed)
+                                       int mode, int th_dist, int check_ori, const uint8_t* q_transient, int32_t* claimed)
 {
     int nmatches = 0;
     orc_frame_grid* g = orc_grid_create(k2, n2, minX, maxX, minY, maxY);
@@ -288,7 +288,7 @@ int orc_search_by_projection_lastframe(const float* qu, const float* qv, const f
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }
         if (bestDist <= th_dist) {
-            claimed[bestIdx2] = i;
+            claimed[bestIdx2] = (q_transient && q_transient[i]) ? -2 - i : i;  /* CurrentFrame.mvpMapPoints[bestIdx2]=pMP; blocks only with observations */
             nmatches++;
             if (check_ori) {
                 int bin = rot_bin(qangle[i], k2[bestIdx2].angle);

@@ -69,10 +69,10 @@ int main()
         }
         std::vector<float> prev(2 * (size_t)n1 + 2), qu(n1 + 1), qv(n1 + 1), qr(n1 + 1), qur(n1 + 1), ang(n1 + 1), ur2(n2 + 1);
         std::vector<int32_t> lvl(n1 + 1), m12(n1 + 1), m21(n2 + 1), claimed(n2 + 1), bi(n1 + 1), bd(n1 + 1);
-        std::vector<uint8_t> valid1(n1 + 1), valid2(n2 + 1);
+        std::vector<uint8_t> valid1(n1 + 1), valid2(n2 + 1), transient(n1 + 1);
         for (int i = 0; i < n1; ++i) {
             prev[2 * i] = k1[i].x; prev[2 * i + 1] = k1[i].y; qu[i] = k1[i].x; qv[i] = k1[i].y; lvl[i] = k1[i].octave;
-            qr[i] = unf(2, 40) * scale[lvl[i]]; qur[i] = qu[i] - unf(1, 30); ang[i] = k1[i].angle; valid1[i] = rng() % 5 != 0;
+            qr[i] = unf(2, 40) * scale[lvl[i]]; qur[i] = qu[i] - unf(1, 30); ang[i] = k1[i].angle; valid1[i] = rng() % 5 != 0; transient[i] = rng() % 3 == 0;
         }
         for (int i = 0; i < n2; ++i) { ur2[i] = rng() % 3 ? k2[i].x - unf(1, 30) : -1.f; valid2[i] = rng() % 5 != 0; }
         int nm = -1;
@@ -84,12 +84,12 @@ int main()
         for (int mode = 0; mode < 3; ++mode) {
             for (int i = 0; i < n2; ++i) claimed[i] = rng() % 7 == 0 ? (1 << 20) : -1;
             EXPECT(orbx_search_by_projection_lastframe(&m, qu.data(), qv.data(), qr.data(), qur.data(), lvl.data(), ang.data(), d1.data(), n1, k2.data(),
-                                                       d2.data(), it % 3 ? ur2.data() : nullptr, n2, 0, W, 0, H, mode, 100, 1, claimed.data(), &nm) == ORBX_OK);
-            for (int i = 0; i < n2; ++i) EXPECT(claimed[i] == -1 || claimed[i] == (1 << 20) || (claimed[i] >= 0 && claimed[i] < n1));
+                                                       d2.data(), it % 3 ? ur2.data() : nullptr, n2, 0, W, 0, H, mode, 100, 1, it % 2 ? transient.data() : nullptr, claimed.data(), &nm) == ORBX_OK);
+            for (int i = 0; i < n2; ++i) EXPECT(claimed[i] == -1 || claimed[i] == (1 << 20) || (claimed[i] >= 0 && claimed[i] < n1) || (claimed[i] <= -2 && -2 - claimed[i] < n1));
         }
         for (int i = 0; i < n2; ++i) claimed[i] = -1;
         EXPECT(orbx_search_by_projection_mappoints(&m, qu.data(), qv.data(), qr.data(), qur.data(), lvl.data(), d1.data(), n1, k2.data(), d2.data(),
-                                                   ur2.data(), n2, 0, W, 0, H, 0.8f, claimed.data(), &nm) == ORBX_OK);
+                                                   ur2.data(), n2, 0, W, 0, H, 0.8f, it % 2 ? nullptr : transient.data(), claimed.data(), &nm) == ORBX_OK);
         for (int i = 0; i < n2; ++i) claimed[i] = rng() % 9 == 0 ? 5 : -1;
         EXPECT(orbx_search_by_projection_keyframe(&m, qu.data(), qv.data(), qr.data(), lvl.data(), d1.data(), n1, k2.data(), d2.data(), n2, 0, W, 0, H,
                                                   claimed.data(), &nm) == ORBX_OK);

@@ -57,9 +57,9 @@ lib.orc_grid_features_in_area.restype = _i; lib.orc_grid_features_in_area.argtyp
 lib.orc_search_for_initialization.restype = _i
 lib.orc_search_for_initialization.argtypes = [_vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _i, _f, _i, _vp]
 lib.orc_search_by_projection_mappoints.restype = _i
-lib.orc_search_by_projection_mappoints.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp]
+lib.orc_search_by_projection_mappoints.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp]
 lib.orc_search_by_projection_lastframe.restype = _i
-lib.orc_search_by_projection_lastframe.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp]
+lib.orc_search_by_projection_lastframe.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _vp]
 lib.orc_stereo_refine.restype = None
 lib.orc_stereo_refine.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp]
 lib.orc_stereo_match.restype = None
@@ -345,7 +345,8 @@ def search_for_triangulation(k1, d1, has_mp1, uright1, nodes1, k2, d2, has_mp2, 
     return m12, n
 
 
-def search_by_projection_mappoints(qu, qv, qr, qur, qlevel, qdesc, k2, d2, uright2, bounds, nnratio, claimed):
+def search_by_projection_mappoints(qu, qv, qr, qur, qlevel, qdesc, k2, d2, uright2, bounds, nnratio, claimed, transient=None):
+    transient = None if transient is None else np.ascontiguousarray(transient, np.uint8)
     f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
     qu, qv, qr, qur, uright2 = f32(qu), f32(qv), f32(qr), f32(qur), f32(uright2)
     qlevel = np.ascontiguousarray(qlevel, np.int32)
@@ -354,11 +355,12 @@ def search_by_projection_mappoints(qu, qv, qr, qur, qlevel, qdesc, k2, d2, urigh
     claimed = np.ascontiguousarray(claimed, np.int32).copy()
     n = lib.orc_search_by_projection_mappoints(_ptr(qu), _ptr(qv), _ptr(qr), _ptr(qur), _ptr(qlevel), _ptr(qdesc), len(qu),
                                                _ptr(k2), _ptr(d2), _ptr(uright2), len(k2), bounds[0], bounds[1], bounds[2], bounds[3],
-                                               nnratio, _ptr(claimed))
+                                               nnratio, _ptr(transient), _ptr(claimed))
     return claimed, n
 
 
-def search_by_projection_lastframe(qu, qv, qradius, qur, qoctave, qangle, qdesc, k2, d2, uright2, bounds, mode, th_dist, check_ori, claimed):
+def search_by_projection_lastframe(qu, qv, qradius, qur, qoctave, qangle, qdesc, k2, d2, uright2, bounds, mode, th_dist, check_ori, claimed, transient=None):
+    transient = None if transient is None else np.ascontiguousarray(transient, np.uint8)
     f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
     qu, qv, qradius, qur, qangle, uright2 = f32(qu), f32(qv), f32(qradius), f32(qur), f32(qangle), f32(uright2)
     qoctave = np.ascontiguousarray(qoctave, np.int32)
@@ -367,7 +369,7 @@ def search_by_projection_lastframe(qu, qv, qradius, qur, qoctave, qangle, qdesc,
     claimed = np.ascontiguousarray(claimed, np.int32).copy()
     n = lib.orc_search_by_projection_lastframe(_ptr(qu), _ptr(qv), _ptr(qradius), _ptr(qur), _ptr(qoctave), _ptr(qangle), _ptr(qdesc), len(qu),
                                                _ptr(k2), _ptr(d2), _ptr(uright2), len(k2), bounds[0], bounds[1], bounds[2], bounds[3],
-                                               mode, th_dist, int(check_ori), _ptr(claimed))
+                                               mode, th_dist, int(check_ori), _ptr(transient), _ptr(claimed))
     return claimed, n
 
 

@@ -203,6 +203,23 @@ def test_search_by_projection_variants(vsa, oracle, matcher, motion_features):
             o = oracle.search_by_projection_lastframe(qu, qv, radius, qur, lvl, kl["angle"], dl, kr, dr, uright, bounds, mode, th_dist, check_ori, claimed0)
             assert g[1] == o[1] and np.array_equal(g[0], o[0])
     assert o[1] > 10
+    # map points without observations (the temporal points of stereo / RGB-D tracking): their matches do not block the
+    # feature (src/ORBmatcher.cc:87-89, :1406-1408), so later queries can overwrite it; the count still goes up each time
+    transient = (rng.random(nq) < 0.5).astype(np.uint8)
+    dup = np.concatenate([np.arange(nq), np.arange(0, nq, 3)])              # repeated queries make overwrites certain
+    a = lambda v: np.ascontiguousarray(np.asarray(v)[dup])
+    radius = (15.0 * scale[lvl]).astype(np.float32)
+    saw_overwrite = False
+    for mode, check_ori in ((0, True), (1, False)):
+        g = matcher.search_by_projection_lastframe(a(qu), a(qv), a(radius), a(qur), a(lvl), a(kl["angle"]), a(dl), kr, dr, uright, bounds, mode, 100, check_ori, claimed0, a(transient))
+        o = oracle.search_by_projection_lastframe(a(qu), a(qv), a(radius), a(qur), a(lvl), a(kl["angle"]), a(dl), kr, dr, uright, bounds, mode, 100, check_ori, claimed0, a(transient))
+        assert g[1] == o[1] and np.array_equal(g[0], o[0])
+        assert (o[0] <= -2).any()
+        saw_overwrite |= o[1] > np.count_nonzero((o[0] != -1) & (o[0] != 0) | ((o[0] == 0) & (claimed0 == -1)))
+    assert saw_overwrite
+    g = matcher.search_by_projection_mappoints(a(qu), a(qv), a(radius), a(qur), a(lvl), a(dl), kr, dr, uright, bounds, 0.9, claimed0, a(transient))
+    o = oracle.search_by_projection_mappoints(a(qu), a(qv), a(radius), a(qur), a(lvl), a(dl), kr, dr, uright, bounds, 0.9, claimed0, a(transient))
+    assert g[1] == o[1] and np.array_equal(g[0], o[0]) and (o[0] <= -2).any()
 
 
 def test_stereo_match(vsa, oracle, matcher, stereo_features):

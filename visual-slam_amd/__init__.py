@@ -104,8 +104,8 @@ _SIGS = {
     "orbx_grid_destroy": (None, [_vp]),
     "orbx_grid_features_in_area": (_i, [_vp, _f, _f, _f, _i, _i, _vp, _i, C.POINTER(_i)]),
     "orbx_search_for_initialization": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _i, _f, _i, _vp, C.POINTER(_i)]),
-    "orbx_search_by_projection_mappoints": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, C.POINTER(_i)]),
-    "orbx_search_by_projection_lastframe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, C.POINTER(_i)]),
+    "orbx_search_by_projection_mappoints": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, C.POINTER(_i)]),
+    "orbx_search_by_projection_lastframe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "orbx_stereo_match": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _f, _f, _vp, _vp]),
     "orbx_stereo_match_batch_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "orbx_distinctive_descriptors": (_i, [_vp, _vp, _vp, _i, _vp]),
@@ -510,7 +510,8 @@ class Matcher:
                                                  _ptr(sc), _ptr(sg), len(sc), int(only_stereo), int(check_ori), _ptr(m12), C.byref(n)))
         return m12, n.value
 
-    def search_by_projection_mappoints(self, qu, qv, qr, qur, qlevel, qdesc, k2, d2, uright2, bounds, nnratio, claimed):
+    def search_by_projection_mappoints(self, qu, qv, qr, qur, qlevel, qdesc, k2, d2, uright2, bounds, nnratio, claimed, transient=None):
+        transient = None if transient is None else np.ascontiguousarray(transient, np.uint8)
         f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
         qu, qv, qr, qur, uright2 = f32(qu), f32(qv), f32(qr), f32(qur), f32(uright2)
         qlevel = np.ascontiguousarray(qlevel, np.int32)
@@ -520,11 +521,12 @@ class Matcher:
         n = C.c_int()
         _check(lib.orbx_search_by_projection_mappoints(self.h, _ptr(qu), _ptr(qv), _ptr(qr), _ptr(qur), _ptr(qlevel), _ptr(qdesc), len(qu),
                                                        _ptr(k2), _ptr(d2), _ptr(uright2), len(k2), bounds[0], bounds[1], bounds[2], bounds[3],
-                                                       nnratio, _ptr(claimed), C.byref(n)))
+                                                       nnratio, _ptr(transient), _ptr(claimed), C.byref(n)))
         return claimed, n.value
 
     def search_by_projection_lastframe(self, qu, qv, qradius, qur, qoctave, qangle, qdesc, k2, d2, uright2, bounds, mode, th_dist,
-                                       check_ori, claimed):
+                                       check_ori, claimed, transient=None):
+        transient = None if transient is None else np.ascontiguousarray(transient, np.uint8)
         f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
         qu, qv, qradius, qur, qangle, uright2 = f32(qu), f32(qv), f32(qradius), f32(qur), f32(qangle), f32(uright2)
         qoctave = np.ascontiguousarray(qoctave, np.int32)
@@ -535,7 +537,7 @@ class Matcher:
         _check(lib.orbx_search_by_projection_lastframe(self.h, _ptr(qu), _ptr(qv), _ptr(qradius), _ptr(qur), _ptr(qoctave), _ptr(qangle),
                                                        _ptr(qdesc), len(qu), _ptr(k2), _ptr(d2), _ptr(uright2), len(k2),
                                                        bounds[0], bounds[1], bounds[2], bounds[3], mode, th_dist, int(check_ori),
-                                                       _ptr(claimed), C.byref(n)))
+                                                       _ptr(transient), _ptr(claimed), C.byref(n)))
         return claimed, n.value
 
     def stereo_match(self, kl, dl, kr, dr, scale_factors, n_rows, min_d, max_d):

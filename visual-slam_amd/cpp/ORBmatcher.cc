@@ -1,4 +1,7 @@
 #include "ORBmatcher.h"
+#ifdef ORBX_MATCHER_CLASS
+#define ORBmatcher ORBX_MATCHER_CLASS      // see ORBmatcher.h
+#endif
 #include <algorithm>
 #include <stdexcept>
 #include <string>
@@ -93,14 +96,15 @@ int ORBmatcher::SearchForInitialization(const FrameView& F1, const FrameView& F2
 
 namespace {
 struct QueryArrays {
-    std::vector<float> u, v, r, ur, angle; std::vector<int32_t> level; std::vector<unsigned char> desc;
+    std::vector<float> u, v, r, ur, angle; std::vector<int32_t> level; std::vector<unsigned char> desc, transient;
     explicit QueryArrays(const std::vector<ProjectedQuery>& q)
     {
         const size_t n = q.size();
-        u.resize(n); v.resize(n); r.resize(n); ur.resize(n); angle.resize(n); level.resize(n); desc.resize(n * 32);
+        u.resize(n); v.resize(n); r.resize(n); ur.resize(n); angle.resize(n); level.resize(n); desc.resize(n * 32); transient.resize(n);
         for (size_t i = 0; i < n; ++i) {
             u[i] = q[i].u; v[i] = q[i].v; r[i] = q[i].radius; ur[i] = q[i].uRight; angle[i] = q[i].angle; level[i] = q[i].level;
             std::memcpy(desc.data() + i * 32, q[i].descriptor, 32);
+            transient[i] = q[i].hasObservations ? 0 : 1;
         }
     }
 };
@@ -115,7 +119,7 @@ int ORBmatcher::SearchByProjection(const FrameView& F, const std::vector<Project
     int nmatches = 0;
     check(orbx_search_by_projection_mappoints(Context(), q.u.data(), q.v.data(), q.r.data(), q.ur.data(), q.level.data(), q.desc.data(),
                                               (int)vQueries.size(), as_orbx(*F.keysUn), d2.data(), F.uRight ? F.uRight->data() : nullptr, n2,
-                                              F.minX, F.maxX, F.minY, F.maxY, mfNNratio, vnClaimed.data(), &nmatches),
+                                              F.minX, F.maxX, F.minY, F.maxY, mfNNratio, q.transient.data(), vnClaimed.data(), &nmatches),
           "SearchByProjection");
     return nmatches;
 }
@@ -131,7 +135,7 @@ int ORBmatcher::SearchByProjection(const FrameView& F, const std::vector<Project
     check(orbx_search_by_projection_lastframe(Context(), q.u.data(), q.v.data(), q.r.data(), q.ur.data(), q.level.data(), q.angle.data(),
                                               q.desc.data(), (int)vQueries.size(), as_orbx(*F.keysUn), d2.data(),
                                               F.uRight ? F.uRight->data() : nullptr, n2, F.minX, F.maxX, F.minY, F.maxY, mode, thDist,
-                                              mbCheckOrientation ? 1 : 0, vnClaimed.data(), &nmatches),
+                                              mbCheckOrientation ? 1 : 0, q.transient.data(), vnClaimed.data(), &nmatches),
           "SearchByProjection");
     return nmatches;
 }

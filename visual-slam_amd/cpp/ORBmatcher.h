@@ -13,6 +13,13 @@
 #include "ORBextractor.h"
 #include "../../include/orbx.h"
 
+// Inside the reference tree the reference keeps its own ORB_SLAM2::ORBmatcher (the Frame& / KeyFrame* signatures,
+// implemented by cpp/reference_adapters/ORBmatcher_adapters.cc on top of this class): build with
+// -DORBX_MATCHER_CLASS=OrbxMatcherEngine there so that the two classes have different names.
+#ifdef ORBX_MATCHER_CLASS
+#define ORBmatcher ORBX_MATCHER_CLASS
+#endif
+
 namespace ORB_SLAM2
 {
 
@@ -33,6 +40,10 @@ struct ProjectedQuery {
     int level;           // predicted level (map points) or octave of the last-frame keypoint
     float angle;         // keypoint angle of the source observation (rotation histogram)
     const unsigned char* descriptor; // 32 bytes
+    // the map point has observations (pMP->Observations() > 0): its match blocks the feature for later queries
+    // (src/ORBmatcher.cc:87-89, :1406-1408).  False for the temporal points of stereo / RGB-D tracking: such a match
+    // is reported as -2 - query in vnClaimed and a later query may take the feature over, as in the reference.
+    bool hasObservations = true;
 };
 
 // What DBoW2::FeatureVector is (Thirdparty/DBoW2/DBoW2/FeatureVector.h:21-22): node id -> indices of the features under it.
@@ -142,5 +153,9 @@ protected:
 };
 
 } // namespace ORB_SLAM2
+
+#ifdef ORBX_MATCHER_CLASS
+#undef ORBmatcher
+#endif
 
 #endif

@@ -125,7 +125,7 @@ int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* k1, con
 int orbx_search_by_projection_mappoints(orbx_matcher* m, const float* qu, const float* qv, const float* qr, const float* qur,
                                         const int32_t* qlevel, const uint8_t* qdesc, int nq,
                                         const orbx_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
-                                        float minX, float maxX, float minY, float maxY, float nnratio, int32_t* claimed, int* nmatches)
+                                        float minX, float maxX, float minY, float maxY, float nnratio, const uint8_t* q_transient, int32_t* claimed, int* nmatches)
 {
     if (!m || !nmatches || nq < 0 || n2 < 0 || !(maxX > minX) || !(maxY > minY)) { set_error("orbx_search_by_projection_mappoints: bad argument"); return ORBX_ERR_BAD_ARG; }
     *nmatches = 0;
@@ -154,7 +154,7 @@ int orbx_search_by_projection_mappoints(orbx_matcher* m, const float* qu, const 
         }
         if (bestDist <= TH_HIGH) {
             if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
-            claimed[bestIdx] = i;
+            claimed[bestIdx] = q_transient && q_transient[i] ? -2 - i : i;     // a point without observations does not block (:87-89)
             ++count;
         }
     }
@@ -167,7 +167,7 @@ int orbx_search_by_projection_lastframe(orbx_matcher* m, const float* qu, const 
                                         const int32_t* qoctave, const float* qangle, const uint8_t* qdesc, int nq,
                                         const orbx_keypoint* k2, const uint8_t* d2, const float* uright2, int n2,
                                         float minX, float maxX, float minY, float maxY, int mode, int th_dist, int check_ori,
-                                        int32_t* claimed, int* nmatches)
+                                        const uint8_t* q_transient, int32_t* claimed, int* nmatches)
 {
     if (!m || !nmatches || nq < 0 || n2 < 0 || !(maxX > minX) || !(maxY > minY) || mode < 0 || mode > 2) { set_error("orbx_search_by_projection_lastframe: bad argument"); return ORBX_ERR_BAD_ARG; }
     *nmatches = 0;
@@ -199,7 +199,7 @@ int orbx_search_by_projection_lastframe(orbx_matcher* m, const float* qu, const 
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }
         if (bestDist <= th_dist) {
-            claimed[bestIdx2] = i;
+            claimed[bestIdx2] = q_transient && q_transient[i] ? -2 - i : i;   // a point without observations does not block (:1406-1408)
             ++count;
             if (check_ori) hist[rotation_bin(qangle[i], k2[bestIdx2].angle)].push_back(bestIdx2);
         }
