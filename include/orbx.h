@@ -224,6 +224,21 @@ int orbx_search_for_initialization(orbx_matcher* m,
                                    float* prev_matched_xy, int window, float nnratio, int check_ori,
                                    int32_t* matches12, int* nmatches);
 
+/* The same search for a batch of frame pairs, everything on the device and no host round trip (one wavefront per pair
+ * walks the queries in order; candidates, distances, the claim / steal step of :447 and :466-473, ratio test, rotation
+ * histogram and the vbPrevMatched update of :518-520 all happen there).  Keypoint, descriptor and count arrays are laid
+ * out like the outputs of orbx_extract_batch_device (pair p at offset p * cap); pass a batch's own outputs, or its
+ * undistorted copy, directly.  d_prev_matched_xy[n_pairs][cap][2] in / out, d_matches12[n_pairs][cap] (-1 past each
+ * count), d_nmatches[n_pairs].  ORBX_ERR_CAPACITY when cap is above 2690 (the pair's octave-0 features live in LDS).
+ * Runs on `stream`; nothing is allocated. */
+int orbx_search_for_initialization_batch_device(orbx_matcher* m,
+                                                const orbx_keypoint* d_k1, const uint8_t* d_d1, const int32_t* d_n1,
+                                                const orbx_keypoint* d_k2, const uint8_t* d_d2, const int32_t* d_n2, int cap, int n_pairs,
+                                                float minX, float maxX, float minY, float maxY,
+                                                float* d_prev_matched_xy, int window, float nnratio, int check_ori,
+                                                int32_t* d_matches12, int32_t* d_nmatches, void* stream);
+
+
 /* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), candidate loop and acceptance
  * (src/ORBmatcher.cc:68-125).  Query i = one visible map point: projection (qu,qv), search radius
  * qr = r*scale[level] (:69), right-image projection qur (:93), predicted level, descriptor.

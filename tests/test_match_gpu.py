@@ -178,6 +178,61 @@ def test_search_for_initialization(vsa, oracle, matcher, motion_features):
     assert g[1] > 20 and (g[0] >= 0).sum() == g[1]
 
 
+def test_search_for_initialization_batch_device(vsa, oracle, matcher):
+    """64 frame pairs straight from orbx_extract_batch_device's output, matched on the device without a host round trip:
+    every pair's vnMatches12, match count and updated vbPrevMatched equal the oracle's sequential routine run on that pair.
+    Second round: the updated vbPrevMatched fed back in with a smaller window (the way the tracker calls it frame after
+    frame); also a pair of empty frames and equal frames (ties everywhere: the visiting order decides)."""
+    import torch
+    w, h, P = 640, 480, 64
+    rng = np.random.default_rng(33)
+    frames = []
+    for p in range(P):
+        a = vsa.synth_frame(700 + p % 20, w, h)
+        if p == 5:
+            a = np.full((h, w), 77, np.uint8)                                       # no keypoints at all
+        b = a if p == 6 else np.clip(np.roll(a, (p % 7 - 3, p % 11 - 5), axis=(0, 1)).astype(np.int32) + rng.integers(-3, 4, a.shape), 0, 255).astype(np.uint8)
+        frames += [a, b]
+    nf = 1000 if True else 0
+    ex = vsa.Extractor(vsa.make_params(nf, 1.2, 4), w, h, max_batch=2 * P, device=0)
+    cap = ex.cap
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+    d_k = torch.zeros((2 * P, cap, 7), dtype=torch.float32, device="cuda")
+    d_d = torch.zeros((2 * P, cap, 32), dtype=torch.uint8, device="cuda")
+    d_c = torch.zeros(2 * P, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ex.extract_batch_device(imgs.data_ptr(), w, w * h, 2 * P, d_k.data_ptr(), d_d.data_ptr(), d_c.data_ptr(), cap, st)
+    # frames 2p and 2p+1 form pair p: de-interleave views (stride 2 over frames) into contiguous per-pair arrays
+    k1 = d_k[0::2].contiguous(); k2 = d_k[1::2].contiguous(); dd1 = d_d[0::2].contiguous(); dd2 = d_d[1::2].contiguous()
+    n1 = d_c[0::2].contiguous(); n2 = d_c[1::2].contiguous()
+    prev = k1[:, :, :2].contiguous()                                              # vbPrevMatched starts at F1's keypoints (src/Tracking.cc:628-630)
+    m12 = torch.full((P, cap), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros(P, dtype=torch.int32, device="cuda")
+    bounds = (0.0, float(w), 0.0, float(h))
+    hk1 = k1.cpu().numpy().view(vsa.KEYPOINT_DTYPE).reshape(P, cap); hk2 = k2.cpu().numpy().view(vsa.KEYPOINT_DTYPE).reshape(P, cap)
+    hd1 = dd1.cpu().numpy(); hd2 = dd2.cpu().numpy(); hn1 = n1.cpu().numpy(); hn2 = n2.cpu().numpy()
+    hprev = prev.cpu().numpy().copy()
+    total = 0
+    for window, ratio, ori in ((100, 0.9, True), (30, 0.8, True), (100, 0.9, False)):
+        matcher.search_for_initialization_batch_device(k1.data_ptr(), dd1.data_ptr(), n1.data_ptr(), k2.data_ptr(), dd2.data_ptr(), n2.data_ptr(),
+                                                       cap, P, bounds, prev.data_ptr(), window, ratio, ori, m12.data_ptr(), nm.data_ptr(), st)
+        torch.cuda.synchronize()
+        gm, gn, gp = m12.cpu().numpy(), nm.cpu().numpy(), prev.cpu().numpy()
+        for p in range(P):
+            a, b = int(hn1[p]), int(hn2[p])
+            om, on, op = oracle.search_for_initialization(hk1[p, :a], hd1[p, :a], hk2[p, :b], hd2[p, :b], bounds, hprev[p, :a], window, ratio, ori)
+            assert gn[p] == on, (p, window, gn[p], on)
+            assert np.array_equal(gm[p, :a], om) and np.all(gm[p, a:] == -1), (p, window)
+            assert np.array_equal(gp[p, :a].view(np.uint32), np.asarray(op, np.float32).reshape(-1, 2).view(np.uint32)), (p, window)
+            hprev[p, :a] = np.asarray(op, np.float32).reshape(-1, 2)
+            total += on
+    assert hn1[5] == 0 and total > 50 * P
+    with pytest.raises(vsa.OrbxError) as e:
+        matcher.search_for_initialization_batch_device(k1.data_ptr(), dd1.data_ptr(), n1.data_ptr(), k2.data_ptr(), dd2.data_ptr(), n2.data_ptr(),
+                                                       3000, P, bounds, prev.data_ptr(), 100, 0.9, True, m12.data_ptr(), nm.data_ptr(), st)
+    assert e.value.status == 4
+    ex.close()
+
+
 def test_search_by_projection_variants(vsa, oracle, matcher, motion_features):
     w, h, kl, dl, kr, dr = motion_features
     rng = np.random.default_rng(9)

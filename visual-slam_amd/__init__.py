@@ -104,6 +104,7 @@ _SIGS = {
     "orbx_grid_destroy": (None, [_vp]),
     "orbx_grid_features_in_area": (_i, [_vp, _f, _f, _f, _i, _i, _vp, _i, C.POINTER(_i)]),
     "orbx_search_for_initialization": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _i, _f, _i, _vp, C.POINTER(_i)]),
+    "orbx_search_for_initialization_batch_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _i, _f, _i, _vp, _vp, _vp]),
     "orbx_search_by_projection_mappoints": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, C.POINTER(_i)]),
     "orbx_search_by_projection_lastframe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "orbx_stereo_match": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _f, _f, _vp, _vp]),
@@ -509,6 +510,13 @@ class Matcher:
                                                  _ptr(k2), _ptr(d2), _ptr(h2), _ptr(u2), len(k2), C.byref(fv2), _ptr(F), ex, ey,
                                                  _ptr(sc), _ptr(sg), len(sc), int(only_stereo), int(check_ori), _ptr(m12), C.byref(n)))
         return m12, n.value
+
+    def search_for_initialization_batch_device(self, d_k1, d_d1, d_n1, d_k2, d_d2, d_n2, cap, n_pairs, bounds, d_prev, window, nnratio,
+                                               check_ori, d_matches12, d_nmatches, stream):
+        """All arguments starting with d_ are device pointers (ints)."""
+        _check(lib.orbx_search_for_initialization_batch_device(self.h, d_k1, d_d1, d_n1, d_k2, d_d2, d_n2, cap, n_pairs, bounds[0], bounds[1],
+                                                               bounds[2], bounds[3], d_prev, window, nnratio, int(check_ori), d_matches12,
+                                                               d_nmatches, stream))
 
     def search_by_projection_mappoints(self, qu, qv, qr, qur, qlevel, qdesc, k2, d2, uright2, bounds, nnratio, claimed, transient=None):
         transient = None if transient is None else np.ascontiguousarray(transient, np.uint8)

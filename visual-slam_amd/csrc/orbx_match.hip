@@ -399,6 +399,189 @@ __global__ __launch_bounds__(1024) void k_window_scan(int32_t* __restrict__ rowp
 }
 
 // rows a right keypoint's band can span: ceil(y + r) - floor(y - r) + 1 <= 2r + 3 with r = 2 * scale
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:408-523) for a batch of frame pairs, every step on the device:
+// one wavefront per pair.  The octave-0 keypoints of frame 2 (the only ones a level-0 window returns, :428) go to LDS
+// with their descriptors; the queries (octave-0 keypoints of frame 1) are then walked IN ORDER, because each accepted
+// match changes what later queries may take (vMatchedDistance / vnMatches21, :447, :466-473).  Per query the 64 lanes
+// share the candidates: window test, Hamming distance, the `vMatchedDistance[i2] <= dist` skip; the best candidate is
+// the minimum of distance << 32 | visiting order, the visiting order of Frame::GetFeaturesInArea being grid column,
+// grid row, keypoint index (src/Frame.cc:350-376: strict `<` lets the first visited of equal distances win); the second
+// best distance is the second smallest of the multiset, which is what the sequential update of :449-459 yields.
+// Rotation histogram, ComputeThreeMaxima, the removal of the other bins and the update of vbPrevMatched follow.
+// LDS per pair: 57 bytes per keypoint of capacity (kInitLdsPerKeypoint).
+// ---------------------------------------------------------------------------------------------
+constexpr int kHistoLength = 30;
+constexpr int kThLow = 50;
+constexpr int kInitLdsPerKeypoint = 57;
+
+__device__ __forceinline__ int rotation_bin_dev(float a1, float a2)      // :476-482 (factor = 1/HISTO_LENGTH: bins 0..12 only)
+{
+    const float factor = 1.0f / kHistoLength;
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));
+    if (bin == kHistoLength) bin = 0;
+    return bin;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restrict__ k1, const uint32_t* __restrict__ d1, const int32_t* __restrict__ n1v,
+                                                   const orbx_keypoint* __restrict__ k2, const uint32_t* __restrict__ d2, const int32_t* __restrict__ n2v,
+                                                   int cap, float minX, float minY, float invW, float invH,
+                                                   float* __restrict__ prev_xy, float window, float nnratio, int check_ori,
+                                                   int32_t* __restrict__ matches12, int32_t* __restrict__ nmatches)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    // frame 2, octave 0, in keypoint order: descriptor, position, visiting-order key, state of the sequential pass
+    uint4* s_desc = reinterpret_cast<uint4*>(smem);                                  // 2 x uint4 per entry
+    float2* s_xy = reinterpret_cast<float2*>(smem + (size_t)cap * 32);
+    uint32_t* s_okey = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 40);         // cellx << 26 | celly << 20 | index
+    int32_t* s_m21 = reinterpret_cast<int32_t*>(smem + (size_t)cap * 44);            // vnMatches21
+    uint16_t* s_mdist = reinterpret_cast<uint16_t*>(smem + (size_t)cap * 48);        // vMatchedDistance (0xFFFF = INT_MAX)
+    uint16_t* s_qlist = reinterpret_cast<uint16_t*>(smem + (size_t)cap * 50);        // octave-0 keypoints of frame 1
+    int32_t* s_m12 = reinterpret_cast<int32_t*>(smem + (size_t)cap * 52);            // vnMatches12
+    uint8_t* s_bin = smem + (size_t)cap * 56;                                        // histogram bin a query was pushed to (255: none)
+    __shared__ int s_hist[kHistoLength];
+
+    const int lane = threadIdx.x;
+    const int pair = blockIdx.x;
+    const size_t off = (size_t)pair * cap;
+    k1 += off; k2 += off; d1 += off * 8; d2 += off * 8; prev_xy += off * 2; matches12 += off;
+    const int n1 = min(n1v[pair], cap), n2 = min(n2v[pair], cap);
+
+    // compaction of the octave-0 keypoints that lie in the 64 x 48 grid (Frame::PosInGrid, src/Frame.cc:382-392)
+    int n0 = 0;
+    for (int j0 = 0; j0 < n2; j0 += 64) {
+        const int j = j0 + lane;
+        bool on = false; float x = 0.f, y = 0.f; int px = 0, py = 0;
+        if (j < n2) {
+            const orbx_keypoint kp = k2[j];
+            x = kp.x; y = kp.y;
+            px = (int)roundf(__fmul_rn(__fsub_rn(x, minX), invW));
+            py = (int)roundf(__fmul_rn(__fsub_rn(y, minY), invH));
+            on = kp.octave == 0 && px >= 0 && px < 64 && py >= 0 && py < 48;
+        }
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int pos = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint4* tp = reinterpret_cast<const uint4*>(d2 + (size_t)j * 8);
+            s_desc[2 * pos] = tp[0]; s_desc[2 * pos + 1] = tp[1];
+            s_xy[pos] = make_float2(x, y);
+            s_okey[pos] = ((uint32_t)px << 26) | ((uint32_t)py << 20) | (uint32_t)j;
+            s_m21[pos] = -1; s_mdist[pos] = 0xFFFFu;
+        }
+        n0 += __popcll(m);
+    }
+    int nq = 0;
+    for (int i0 = 0; i0 < n1; i0 += 64) {
+        const int i = i0 + lane;
+        const bool on = i < n1 && k1[i].octave <= 0;                       // :424-426 skips level1 > 0
+        const unsigned long long m = __ballot(on);
+        if (on) s_qlist[nq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+        nq += __popcll(m);
+        if (i < n1) { s_m12[i] = -1; s_bin[i] = 255; }
+    }
+    if (lane < kHistoLength) s_hist[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    int count = 0;
+    // the next query's descriptor and window centre are fetched while the current one is matched
+    uint32_t qd[8]; float qx = 0.f, qy = 0.f; int qi = -1;
+    auto fetch = [&](int e) {
+        if (e < nq) {
+            qi = s_qlist[e];
+            const uint4* tp = reinterpret_cast<const uint4*>(d1 + (size_t)qi * 8);
+            const uint4 lo = tp[0], hi = tp[1];
+            qd[0] = lo.x; qd[1] = lo.y; qd[2] = lo.z; qd[3] = lo.w; qd[4] = hi.x; qd[5] = hi.y; qd[6] = hi.z; qd[7] = hi.w;
+            qx = prev_xy[2 * qi]; qy = prev_xy[2 * qi + 1];
+        }
+    };
+    fetch(0);
+    for (int e = 0; e < nq; ++e) {
+        const int i1 = qi;
+        uint32_t cd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cd[k] = qd[k];
+        const float cx = qx, cy = qy;
+        fetch(e + 1);
+        unsigned long long best = ~0ull;                                   // distance << 32 | visiting order
+        int second = INT_MAX, bestj = -1;
+        for (int j0 = 0; j0 < n0; j0 += 64) {
+            const int j = j0 + lane;
+            if (j >= n0) continue;
+            const float2 p = s_xy[j];
+            if (!(fabsf(__fsub_rn(p.x, cx)) < window && fabsf(__fsub_rn(p.y, cy)) < window)) continue;     // src/Frame.cc:370-374
+            const uint4 lo = s_desc[2 * j], hi = s_desc[2 * j + 1];
+            const int dist = __popc(cd[0] ^ lo.x) + __popc(cd[1] ^ lo.y) + __popc(cd[2] ^ lo.z) + __popc(cd[3] ^ lo.w) +
+                             __popc(cd[4] ^ hi.x) + __popc(cd[5] ^ hi.y) + __popc(cd[6] ^ hi.z) + __popc(cd[7] ^ hi.w);
+            if ((int)s_mdist[j] <= dist) continue;                         // :447 (0xFFFF stands for INT_MAX)
+            const unsigned long long key = ((unsigned long long)(uint32_t)dist << 32) | s_okey[j];
+            if (key < best) { if (best != ~0ull) second = (int)(best >> 32); best = key; bestj = j; }
+            else if (dist < second) second = dist;
+        }
+        const unsigned long long wbest = wave_min_u64(best);
+        if (wbest == ~0ull) continue;                                      // no candidate passed
+        const bool winner = best == wbest;                                 // keys are unique: one lane
+        const int mine = winner ? second : (best == ~0ull ? INT_MAX : (int)(best >> 32));
+        const int bestDist2 = wave_min_i32(mine);
+        const int bestDist = (int)(wbest >> 32);
+        if (bestDist <= kThLow && (float)bestDist < __fmul_rn((float)bestDist2, nnratio)) {       // :462-464
+            const int wj = __builtin_amdgcn_readfirstlane(__shfl(bestj, __ffsll((long long)__ballot(winner)) - 1, 64));
+            const int i2 = (int)(s_okey[wj] & 0xFFFFFu);
+            if (lane == 0) {
+                const int prev = s_m21[wj];
+                if (prev >= 0) s_m12[prev] = -1;                           // :466-470
+                s_m12[i1] = i2; s_m21[wj] = i1; s_mdist[wj] = (uint16_t)bestDist;
+                if (check_ori) { const int bin = rotation_bin_dev(k1[i1].angle, k2[i2].angle); s_bin[i1] = (uint8_t)bin; ++s_hist[bin]; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+    // rotation consistency (:489-515)
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    if (check_ori) {
+        int m1 = 0, m2 = 0, m3 = 0;
+        for (int i = 0; i < kHistoLength; ++i) {                           // ComputeThreeMaxima, :1604-1645 (uniform: every lane the same)
+            const int sz = s_hist[i];
+            if (sz > m1) { m3 = m2; m2 = m1; m1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > m2) { m3 = m2; m2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > m3) { m3 = sz; ind3 = i; }
+        }
+        if ((float)m2 < __fmul_rn(0.1f, (float)m1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)m3 < __fmul_rn(0.1f, (float)m1)) ind3 = -1;
+    }
+    for (int i0 = 0; i0 < n1; i0 += 64) {
+        const int i = i0 + lane;
+        int mt = -1;
+        if (i < n1) {
+            mt = s_m12[i];
+            const int bin = s_bin[i];
+            if (check_ori && bin != 255 && bin != ind1 && bin != ind2 && bin != ind3) mt = -1;
+            matches12[i] = mt;
+            if (mt >= 0) { prev_xy[2 * i] = k2[mt].x; prev_xy[2 * i + 1] = k2[mt].y; }         // :518-520
+        }
+        count += __popcll(__ballot(mt >= 0));
+    }
+    for (int i = n1 + lane; i < cap; i += 64) matches12[i] = -1;
+    if (lane == 0) nmatches[pair] = count;
+}
+
 static int stereo_band_rows(const float* scale_factors, int nlevels)
 {
     float smax = 0.f;
@@ -627,6 +810,26 @@ int orbx_hamming_csr(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(dist_out, m->stage[5], sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, m->stream));
     HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbx_search_for_initialization_batch_device(orbx_matcher* m, const orbx_keypoint* d_k1, const uint8_t* d_d1, const int32_t* d_n1,
+                                                const orbx_keypoint* d_k2, const uint8_t* d_d2, const int32_t* d_n2, int cap, int n_pairs,
+                                                float minX, float maxX, float minY, float maxY, float* d_prev_matched_xy, int window,
+                                                float nnratio, int check_ori, int32_t* d_matches12, int32_t* d_nmatches, void* stream)
+{
+    if (!m || cap < 1 || n_pairs < 0 || !(maxX > minX) || !(maxY > minY)) { set_error("orbx_search_for_initialization_batch_device: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (n_pairs == 0) return ORBX_OK;
+    if (!d_k1 || !d_d1 || !d_n1 || !d_k2 || !d_d2 || !d_n2 || !d_prev_matched_xy || !d_matches12 || !d_nmatches) { set_error("orbx_search_for_initialization_batch_device: null pointer"); return ORBX_ERR_BAD_ARG; }
+    const size_t lds = (size_t)cap * kInitLdsPerKeypoint + 16;
+    if (lds > 150 * 1024 || cap >= (1 << 16)) { set_error("orbx_search_for_initialization_batch_device: per-frame capacity above 2690 keypoints does not fit the LDS of one CU"); return ORBX_ERR_CAPACITY; }
+    HIP_CHECK(hipSetDevice(m->device));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_init_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const float invW = 64.0f / (maxX - minX), invH = 48.0f / (maxY - minY);      // Frame::mfGridElementWidthInv / HeightInv, src/Frame.cc:101-102
+    hipLaunchKernelGGL(k_init_match, dim3(n_pairs), dim3(64), lds, (hipStream_t)stream, d_k1, reinterpret_cast<const uint32_t*>(d_d1), d_n1,
+                       d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_n2, cap, minX, minY, invW, invH, d_prev_matched_xy, (float)window, nnratio,
+                       check_ori, d_matches12, d_nmatches);
+    HIP_CHECK(hipGetLastError());
     return ORBX_OK;
 }
 
