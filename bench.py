@@ -482,8 +482,10 @@ def worker(a):
                                           f"one batch of {a.kitti_frames} HBM-resident 1241x376 frames, nFeatures=2000, split over the ranks "
                                           "(BASELINE configs[2]; one step = the whole batch)"))
         torch.cuda.empty_cache()
-        configs.append(leg_config_extract(cx, vsa, np, "uhd_3840x2160", 3840, 2160, 8000, 12, 32, False, 2, 16, max(2, min(a.steps, 10)), 1,
-                                          "32 HBM-resident 3840x2160 frames per GPU per step, nFeatures=8000, 12 levels (BASELINE configs[3])"))
+        configs.append(leg_config_extract(cx, vsa, np, "uhd_3840x2160", 3840, 2160, 8000, 12, 128, False, 2, 64, max(2, min(a.steps, 6)), 1,
+                                          "128 HBM-resident 3840x2160 frames per GPU per step (two contexts of 64: a level's quadtree is "
+                                          "one workgroup, so a 16-frame batch leaves most CUs idle during that stage), nFeatures=8000, "
+                                          "12 levels (BASELINE configs[3])"))
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ Hamming workload

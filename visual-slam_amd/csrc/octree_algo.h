@@ -159,12 +159,18 @@ static OT_DEV void ot_child_box(const OtNode& p, int q, OtNode& c)
 // Key storage.  Thread tid owns the keys tid, tid+nt, tid+2nt, ... ("slot" j = key tid + j*nt) for the whole
 // run, and only the owner ever touches a key's node id.  The arrays live in LDS when a level's keys fit
 // there and in device memory otherwise.
-struct OtMemKeys {
+// LOOK: how many keys a thread looks up before it commits them (ot_for_keys_pipelined): 4 hides the LDS latency;
+// arrays in device memory want 16 (a round trip there costs about as much as a whole group's arithmetic, and a level
+// of a 3840 x 2160 image gives every thread some ninety keys per pass).
+template <int LOOK>
+struct OtMemKeysT {
+    static constexpr int kLook = LOOK;
     const uint32_t* keys; uint16_t* node; int nk;
     OT_DEV uint32_t key(int, int k) const { return keys[k]; }
     OT_DEV uint16_t get(int, int k) const { return node[k]; }
     OT_DEV void set(int, int k, uint16_t v) { node[k] = v; }
 };
+typedef OtMemKeysT<4> OtMemKeys;
 // f(slot, key index) for every key the calling thread owns
 template <class KS, class F>
 static OT_DEV void ot_for_keys(KS& ks, int tid, int nt, F&& f)
@@ -180,17 +186,18 @@ static OT_DEV void ot_for_keys(KS& ks, int tid, int nt, F&& f)
 template <class KS, class L, class C>
 static OT_DEV void ot_for_keys4(KS& ks, int tid, int nt, L&& look, C&& commit)
 {
+    constexpr int U = KS::kLook;
     int j = 0;
-    for (int k0 = 0; k0 < ks.nk; k0 += 4 * nt, j += 4) {
-        const int k = k0 + tid, k1 = k + nt, k2 = k + 2 * nt, k3 = k + 3 * nt;
-        const int v0 = k < ks.nk ? look(j, k) : -1;
-        const int v1 = k1 < ks.nk ? look(j + 1, k1) : -1;
-        const int v2 = k2 < ks.nk ? look(j + 2, k2) : -1;
-        const int v3 = k3 < ks.nk ? look(j + 3, k3) : -1;
-        commit(j, k, v0);
-        commit(j + 1, k1, v1);
-        commit(j + 2, k2, v2);
-        commit(j + 3, k3, v3);
+    for (int k0 = 0; k0 < ks.nk; k0 += U * nt, j += U) {
+        int v[U];
+#ifndef ORBX_OCTREE_HOST_SIM
+#pragma unroll
+#endif
+        for (int u = 0; u < U; ++u) { const int k = k0 + tid + u * nt; v[u] = k < ks.nk ? look(j + u, k) : -1; }
+#ifndef ORBX_OCTREE_HOST_SIM
+#pragma unroll
+#endif
+        for (int u = 0; u < U; ++u) commit(j + u, k0 + tid + u * nt, v[u]);
     }
 }
 
@@ -379,17 +386,22 @@ static OT_DEV void ot_split_step(OtShared& s, KS& ks, int N, int fine)
     }
     OT_SYNC();
     // keys follow their nodes
-    ot_for_keys(ks, tid, nt, [&](int j, int k) {
-        const uint16_t p = ks.get(j, k);
-        if (p == kOtDead) return;
-        const int e = s.posToCand[p];
-        if (s.pi[e] <= rstar) {
-            const uint32_t key = ks.key(j, k);
-            const int np = s.cc[4 * e + ot_quadrant(s.cur[p], key)];
-            if (s.nxt[np].cnt == 1) { s.nxt[np].aux = key; ks.set(j, k, kOtDead); }
+    ot_for_keys4(ks, tid, nt,
+        [&](int j, int k) -> int {
+            const uint16_t p = ks.get(j, k);
+            if (p == kOtDead) return -1;
+            const int e = s.posToCand[p];
+            if (e >= 0 && s.pi[e] <= rstar) {
+                const int np = s.cc[4 * e + ot_quadrant(s.cur[p], ks.key(j, k))];
+                return s.nxt[np].cnt == 1 ? np | kOtSingle : np;
+            }
+            return s.keep[p];
+        },
+        [&](int j, int k, int np) {
+            if (np < 0) return;
+            if (np & kOtSingle) { s.nxt[np & 0xFFFF].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
             else ks.set(j, k, (uint16_t)np);
-        } else ks.set(j, k, (uint16_t)s.keep[p]);
-    });
+        });
     OT_SYNC();
     if (tid == 0) {
         s.scal[OT_N] = C + (n - nsplit);
@@ -470,11 +482,14 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
     unsigned* best = reinterpret_cast<unsigned*>(s.keep);
     for (int p = tid; p < n; p += nt) best[p] = 0;
     OT_SYNC();
-    ot_for_keys(ks, tid, nt, [&](int j, int k) {
-        const uint16_t p = ks.get(j, k);
-        if (p == kOtDead) return;
-        ot_atomic_max(&best[p], ((ks.key(j, k) & 0xFFu) << 24) | (0xFFFFFFu - (unsigned)k));
-    });
+    ot_for_keys4(ks, tid, nt,
+        [&](int j, int k) -> int {
+            const uint16_t p = ks.get(j, k);
+            return p == kOtDead ? -1 : (int)(((unsigned)p << 8) | (ks.key(j, k) & 0xFFu));      // node, response
+        },
+        [&](int, int k, int v) {
+            if (v >= 0) ot_atomic_max(&best[v >> 8], ((unsigned)(v & 0xFF) << 24) | (0xFFFFFFu - (unsigned)k));
+        });
     OT_SYNC();
     for (int p = tid; p < n && p < outCap; p += nt) {
         const OtNode& nd = s.cur[p];

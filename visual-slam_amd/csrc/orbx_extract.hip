@@ -764,6 +764,7 @@ size_t ot_lds_bytes(int NC, int nthreads, int KL)
 
 // gathers the per-cell candidate slots of a level into the dense key array K (cell-row-major, raster inside a cell: the
 // reference's vToDistributeKeys order) and runs the quadtree on it
+template <int LOOK>
 __device__ __attribute__((always_inline)) int octree_level(OtShared& s, uint32_t* K, uint16_t* NO, int nk, const DevLevel& L,
                                                             const CellRec* __restrict__ cells, const uint16_t* __restrict__ cnt,
                                                             const uint32_t* __restrict__ slots, int NCmax, uint32_t* __restrict__ out)
@@ -786,7 +787,7 @@ __device__ __attribute__((always_inline)) int octree_level(OtShared& s, uint32_t
     }
     __threadfence_block();
     __syncthreads();
-    OtMemKeys ks{K, NO, nk};
+    OtMemKeysT<LOOK> ks{K, NO, nk};
     return ot_distribute(s, ks, K, L.maxBorderY - kMinBorder, L.nIni, L.hX, L.quota, out, L.kp_cap);
 }
 
@@ -832,10 +833,10 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
     // copy gets DS instructions (a pointer chosen at run time would make every key access a FLAT one)
     int n;
     if (nk <= KL)
-        n = octree_level(s, reinterpret_cast<uint32_t*>(ot_mem + keyOff), reinterpret_cast<uint16_t*>(ot_mem + keyOff + (size_t)KL * 4), nk,
+        n = octree_level<4>(s, reinterpret_cast<uint32_t*>(ot_mem + keyOff), reinterpret_cast<uint16_t*>(ot_mem + keyOff + (size_t)KL * 4), nk,
                          L, cells, cnt, slots, NCmax, lvlkp + (unsigned long long)frame * kp_total + L.kp_offset);
     else
-        n = octree_level(s, keys + (unsigned long long)frame * key_total + L.key_offset,
+        n = octree_level<4>(s, keys + (unsigned long long)frame * key_total + L.key_offset,
                          nodeOf + (unsigned long long)frame * key_total + L.key_offset, nk,
                          L, cells, cnt, slots, NCmax, lvlkp + (unsigned long long)frame * kp_total + L.kp_offset);
     if (tid == 0) lvlcnt[frame * nlevels + level] = min(n, L.kp_cap);
