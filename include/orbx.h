@@ -102,7 +102,10 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* image, ptrdiff_t stride,
 /* The same for n_frames host images (uploaded, processed as one batch, downloaded). */
 int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_stride, ptrdiff_t frame_stride,
                        int n_frames, orbx_keypoint* kps, uint8_t* desc, int32_t* counts, int cap_per_frame);
-/* Device-resident batch: images, keypoints, descriptors and counts all in HBM; asynchronous. */
+/* Device-resident batch: images, keypoints, descriptors and counts all in HBM; asynchronous, on `stream`.  The calls
+ * that read the context's state of the last batch afterwards (orbx_pyramid_level(s), the orbx_debug_* taps,
+ * orbx_stereo_refine_batch_device on any stream) order themselves behind it through an event the batch records: the
+ * caller needs no synchronisation of its own for them, only for its own reads of the output arrays. */
 int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdiff_t row_stride,
                               ptrdiff_t frame_stride, int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc,
                               int32_t* d_counts, int cap_per_frame, void* stream);

@@ -6,7 +6,7 @@
   optional pass: SQ_INSTS_VALU GRBM_GUI_ACTIVE                                 (vector-ALU issue share per kernel)
 bytes read = 32*n32 + 64*n64 + 128*n128, bytes written = 32*units.  (FETCH_SIZE tallies gfx950's 128-byte
 requests at 64 bytes; the per-size counters do not.)  Writes profiles/traffic.json, keyed by bench.py's stages.
-usage: pmc_traffic.py <dir with the passes' counter_collection.csv> <out.json> [resize launches per step]"""
+usage: pmc_traffic.py <dir with the passes' counter_collection.csv> <out.json> [resize launches per step] [build stamp]"""
 import collections
 import csv
 import glob
@@ -16,6 +16,7 @@ import sys
 
 root, out = sys.argv[1], sys.argv[2]
 resizes = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+stamp = sys.argv[4] if len(sys.argv) > 4 else None      # orbx_build_stamp() of the library the passes ran on
 tab = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -35,7 +36,7 @@ for k, d in mean.items():
 tot = lambda k, n=1: n * (kern.get(k, {}).get("read_bytes", 0) + kern.get(k, {}).get("write_bytes", 0))
 stages = {"pyramid": tot("k_level0") + tot("k_resize", resizes) + tot("k_borders"), "fast": tot("k_fast_cells"),
           "octree": tot("k_octree"), "describe": tot("k_blur") + tot("k_describe")}
-json.dump({"source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_WRITE_DRAM_32B_sum over "
+json.dump({"build_stamp": stamp, "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_WRITE_DRAM_32B_sum over "
                      "bench.py --contexts 1 (640x480, 256 frames per launch); k_resize is the mean of its launches "
                      f"times {resizes}", "kernels_mean_per_launch": kern, "stages": stages}, open(out, "w"), indent=1)
 print(json.dumps(stages))

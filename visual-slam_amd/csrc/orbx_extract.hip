@@ -1557,10 +1557,19 @@ struct orbx_extractor {
     bool profiling = false;
 
     hipEvent_t ev[ORBX_STAGE_COUNT + 1] = {};
+    hipEvent_t ev_done = nullptr;        // recorded behind the last kernel of every batch, on the stream the batch ran on
+    void* sr_dev = nullptr; uint8_t* sr_pin = nullptr; size_t sr_bytes = 0;   // staging of the host form of the stereo refinement
     hipStream_t copy_stream = nullptr;   // uploads of the chunked host batch path
     std::vector<hipEvent_t> chunk_ev;    // one per chunk: upload done
     float stage_ms[ORBX_STAGE_COUNT] = {};
 };
+
+// The context's own stream catches up with the last batch (which may have run on a caller's stream), then the host waits.
+static hipError_t sync_context(orbx_extractor* ex)
+{
+    const hipError_t e = hipStreamWaitEvent(ex->stream, ex->ev_done, 0);
+    return e != hipSuccess ? e : hipStreamSynchronize(ex->stream);
+}
 
 static int select_device(int device)
 {
@@ -1627,6 +1636,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     }
     ex->key_total = key_off;
     ex->NCmax = std::max(ncmax + 8, 64);
+    if (ex->NCmax >= 65535) { set_error("a level's quota of 65527 keypoints or more overflows the quadtree's 16-bit node ids"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     // LDS key arrays: as many keys as leave five workgroups resident per CU (160 KB / 5 each); residency matters
     // more than keeping the largest level's keys out of device memory (measured at 640x480: 3 resident 0.144 ms,
     // 5 resident 0.110 ms per 256 frames).  Below 512 keys the LDS arrays are not worth having.
@@ -1650,6 +1660,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     }
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ex->oct_lds));
     HIP_CHECK(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ex->ev_done, hipEventDisableTiming));
     const size_t B = (size_t)max_batch;
     HIP_CHECK(hipMalloc(&ex->d_lv, sizeof(DevLevel) * geo.nlevels));
     HIP_CHECK(hipMalloc(&ex->d_cells, sizeof(CellRec) * std::max<size_t>(geo.cells.size(), 1)));
@@ -1715,6 +1726,9 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     for (auto& e : ex->ev) if (e) (void)hipEventDestroy(e);
     if (ex->graph1) (void)hipGraphExecDestroy(ex->graph1);
     for (hipEvent_t e : ex->chunk_ev) (void)hipEventDestroy(e);
+    if (ex->ev_done) (void)hipEventDestroy(ex->ev_done);
+    if (ex->sr_dev) (void)hipFree(ex->sr_dev);
+    if (ex->sr_pin) (void)hipHostFree(ex->sr_pin);
     if (ex->copy_stream) (void)hipStreamDestroy(ex->copy_stream);
     if (ex->stream) (void)hipStreamDestroy(ex->stream);
     delete ex;
@@ -1812,6 +1826,11 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
     HIP_CHECK(hipGetLastError());
+    // what reads this batch's pyramids or tables on another stream waits for this event (not recorded while the
+    // single-frame sequence is being captured into its graph: that sequence only ever runs on the context's own stream)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    HIP_CHECK(hipStreamIsCapturing(st, &capturing));
+    if (capturing == hipStreamCaptureStatusNone) HIP_CHECK(hipEventRecord(ex->ev_done, st));
     return ORBX_OK;
 }
 
@@ -1835,7 +1854,7 @@ int orbx_extractor_set_input_format(orbx_extractor* ex, int format)
     const int channels = format == ORBX_INPUT_GRAY ? 1 : (format == ORBX_INPUT_RGB || format == ORBX_INPUT_BGR ? 3 : 4);
     const bool blue_first = format == ORBX_INPUT_BGR || format == ORBX_INPUT_BGRA;
     HIP_CHECK(hipSetDevice(ex->device));
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     if (channels != ex->channels) {              // the image staging buffers are sized by the input layout
         if (ex->d_img) (void)hipFree(ex->d_img);
         if (ex->h_img) (void)hipHostFree(ex->h_img);
@@ -1885,7 +1904,7 @@ int orbx_undistort_points(orbx_extractor* ex, const orbx_camera* cam, const floa
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(ex->h_pts + 2 * (size_t)ex->pts_cap, ex->d_pts + 2 * (size_t)ex->pts_cap, sizeof(float) * 2 * (size_t)n,
                              hipMemcpyDeviceToHost, ex->stream));
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     std::memcpy(xy_out, ex->h_pts + 2 * (size_t)ex->pts_cap, sizeof(float) * 2 * (size_t)n);
     return ORBX_OK;
 }
@@ -1953,7 +1972,7 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_
                                      hipMemcpyDeviceToHost, ex->stream));
         }
         ex->last_frames = n_frames;
-        HIP_CHECK(hipStreamSynchronize(ex->stream));
+        HIP_CHECK(sync_context(ex));
         int status = ORBX_OK;
         for (int f = 0; f < n_frames; ++f) {
             counts[f] = ex->h_ocount[f];
@@ -2004,7 +2023,7 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_
         if (rc) return rc;
         ex->last_frames = n_frames;
     }
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     if (!one_trip) {
         for (int f = 0; f < n_frames; ++f) {
             const int n = std::min(ex->h_ocount[f], G.out_cap);
@@ -2014,7 +2033,7 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_
             HIP_CHECK(hipMemcpyAsync(ex->h_odesc + (size_t)f * G.out_cap * 32, ex->d_odesc + (size_t)f * G.out_cap * 32, (size_t)32 * n,
                                      hipMemcpyDeviceToHost, ex->stream));
         }
-        HIP_CHECK(hipStreamSynchronize(ex->stream));
+        HIP_CHECK(sync_context(ex));
     }
     int status = ORBX_OK;
     for (int f = 0; f < n_frames; ++f) {
@@ -2057,11 +2076,11 @@ int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, p
     const LevelGeom& L = ex->geo.lv[level];
     if (dst_stride < L.w + 2 * kEdge) return ORBX_ERR_BAD_ARG;
     HIP_CHECK(hipSetDevice(ex->device));
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     // the batch path fills only the 3 innermost frame pixels: complete this level's frame first
     hipLaunchKernelGGL(k_borders, dim3((ex->hlv[level].border_threads + 255) / 256), dim3(256), 0, ex->stream,
                        ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes, 0ull, ex->d_lv + level, kEdge, 8, 1 << 20);
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     // one contiguous copy of the padded level into a pinned buffer, then the rows to the caller (a pageable 2-D copy
     // costs milliseconds)
     const size_t bytes = (size_t)L.stride * L.rows;
@@ -2072,7 +2091,7 @@ int orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* dst, p
         ex->h_level_bytes = bytes;
     }
     HIP_CHECK(hipMemcpyAsync(ex->h_level, ex->d_pyr + (size_t)frame * ex->geo.pyr_bytes + L.offset, bytes, hipMemcpyDeviceToHost, ex->stream));
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     for (int y = 0; y < L.rows; ++y)
         std::memcpy(dst + (size_t)y * dst_stride, ex->h_level + (size_t)y * L.stride + (kRoiX - kEdge), (size_t)L.w + 2 * kEdge);
     return ORBX_OK;
@@ -2096,7 +2115,7 @@ int orbx_pyramid_levels(orbx_extractor* ex, int frame, uint8_t* const* dst, cons
         ex->h_level_bytes = G.pyr_bytes;
     }
     HIP_CHECK(hipMemcpyAsync(ex->h_level, ex->d_pyr + (size_t)frame * G.pyr_bytes, G.pyr_bytes, hipMemcpyDeviceToHost, ex->stream));
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     for (int l = 0; l < G.nlevels; ++l) {
         const LevelGeom& L = G.lv[l];
         for (int y = 0; y < L.rows; ++y)
@@ -2122,6 +2141,8 @@ int orbx_stereo_refine_batch_device(orbx_extractor* left, orbx_extractor* right,
     }
     HIP_CHECK(hipSetDevice(left->device));
     hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipStreamWaitEvent(st, left->ev_done, 0));       // the pyramids of both contexts' last batches must be complete
+    HIP_CHECK(hipStreamWaitEvent(st, right->ev_done, 0));
     hipLaunchKernelGGL(k_stereo_refine, dim3((cap_per_frame + 3) / 4, n_pairs), dim3(256), 0, st, left->d_pyr, right->d_pyr,
                        (unsigned long long)left->geo.pyr_bytes, left->d_lv, left->geo.nlevels, d_kl, d_nl, d_kr, cap_per_frame,
                        d_best_dist, d_best_idx, bf, min_d, max_d, d_uright, d_depth, d_sad);
@@ -2141,32 +2162,38 @@ int orbx_stereo_refine(orbx_extractor* left, orbx_extractor* right, const orbx_k
         if (best_dist[i] >= 0 && (best_idx[i] < 0 || best_idx[i] >= nr)) { set_error("orbx_stereo_refine: best_idx out of range"); return ORBX_ERR_BAD_ARG; }
     HIP_CHECK(hipSetDevice(left->device));
     const int cap = std::max(nl, std::max(nr, 1));
-    orbx_keypoint *d_kl = nullptr, *d_kr = nullptr; int32_t *d_i = nullptr; float* d_f = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_kl); (void)hipFree(d_kr); (void)hipFree(d_i); (void)hipFree(d_f); };
-    int rc = ORBX_OK;
-    do {
-        if (hipMalloc(&d_kl, sizeof(orbx_keypoint) * cap) != hipSuccess || hipMalloc(&d_kr, sizeof(orbx_keypoint) * cap) != hipSuccess ||
-            hipMalloc(&d_i, sizeof(int32_t) * (3 * (size_t)cap + 1)) != hipSuccess || hipMalloc(&d_f, sizeof(float) * 2 * (size_t)cap) != hipSuccess) {
-            set_error("orbx_stereo_refine: hipMalloc failed"); rc = ORBX_ERR_HIP; break;
-        }
-        hipStream_t st = left->stream;
-        (void)hipStreamSynchronize(right->stream);
-        bool ok = hipMemcpyAsync(d_kl, kl, sizeof(orbx_keypoint) * nl, hipMemcpyHostToDevice, st) == hipSuccess;
-        if (nr) ok = ok && hipMemcpyAsync(d_kr, kr, sizeof(orbx_keypoint) * nr, hipMemcpyHostToDevice, st) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d_i, best_dist, sizeof(int32_t) * nl, hipMemcpyHostToDevice, st) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d_i + cap, best_idx, sizeof(int32_t) * nl, hipMemcpyHostToDevice, st) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d_i + 3 * (size_t)cap, &nl, sizeof(int32_t), hipMemcpyHostToDevice, st) == hipSuccess;
-        if (!ok) { set_error("orbx_stereo_refine: upload failed"); rc = ORBX_ERR_HIP; break; }
-        rc = orbx_stereo_refine_batch_device(left, right, d_kl, d_i + 3 * (size_t)cap, d_kr, cap, 1, d_i, d_i + cap, bf, min_d, max_d,
-                                             d_f, d_f + cap, d_i + 2 * (size_t)cap, st);
-        if (rc != ORBX_OK) break;
-        ok = hipMemcpyAsync(uright, d_f, sizeof(float) * nl, hipMemcpyDeviceToHost, st) == hipSuccess &&
-             hipMemcpyAsync(depth, d_f + cap, sizeof(float) * nl, hipMemcpyDeviceToHost, st) == hipSuccess &&
-             hipStreamSynchronize(st) == hipSuccess;
-        if (!ok) { set_error("orbx_stereo_refine: download failed"); rc = ORBX_ERR_HIP; }
-    } while (0);
-    cleanup();
-    return rc;
+    // one pinned block up ([left keypoints | right keypoints | best_dist | best_idx | nl]), one device block
+    // (the same, then sad | uright | depth), one block down; both grow with the frame and stay with the left context
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_kl = 0, o_kr = o_kl + up(sizeof(orbx_keypoint) * cap), o_bd = o_kr + up(sizeof(orbx_keypoint) * cap),
+                 o_bi = o_bd + up(sizeof(int32_t) * cap), o_nl = o_bi + up(sizeof(int32_t) * cap), o_in_end = o_nl + 256,
+                 o_sad = o_in_end, o_ur = o_sad + up(sizeof(int32_t) * cap), o_dp = o_ur + up(sizeof(float) * cap), o_end = o_dp + up(sizeof(float) * cap);
+    if (left->sr_bytes < o_end) {
+        if (left->sr_dev) (void)hipFree(left->sr_dev);
+        if (left->sr_pin) (void)hipHostFree(left->sr_pin);
+        left->sr_dev = nullptr; left->sr_pin = nullptr; left->sr_bytes = 0;
+        HIP_CHECK(hipMalloc(&left->sr_dev, o_end));
+        HIP_CHECK(hipHostMalloc((void**)&left->sr_pin, o_end, hipHostMallocDefault));
+        left->sr_bytes = o_end;
+    }
+    uint8_t* h = left->sr_pin; uint8_t* d = static_cast<uint8_t*>(left->sr_dev);
+    std::memcpy(h + o_kl, kl, sizeof(orbx_keypoint) * nl);
+    if (nr) std::memcpy(h + o_kr, kr, sizeof(orbx_keypoint) * nr);
+    std::memcpy(h + o_bd, best_dist, sizeof(int32_t) * nl);
+    std::memcpy(h + o_bi, best_idx, sizeof(int32_t) * nl);
+    std::memcpy(h + o_nl, &nl, sizeof(int32_t));
+    hipStream_t st = left->stream;
+    HIP_CHECK(hipMemcpyAsync(d, h, o_in_end, hipMemcpyHostToDevice, st));
+    const int rc = orbx_stereo_refine_batch_device(left, right, reinterpret_cast<const orbx_keypoint*>(d + o_kl), reinterpret_cast<const int32_t*>(d + o_nl),
+                                                   reinterpret_cast<const orbx_keypoint*>(d + o_kr), cap, 1, reinterpret_cast<const int32_t*>(d + o_bd),
+                                                   reinterpret_cast<const int32_t*>(d + o_bi), bf, min_d, max_d, reinterpret_cast<float*>(d + o_ur),
+                                                   reinterpret_cast<float*>(d + o_dp), reinterpret_cast<int32_t*>(d + o_sad), st);
+    if (rc != ORBX_OK) return rc;
+    HIP_CHECK(hipMemcpyAsync(h + o_ur, d + o_ur, o_end - o_ur, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::memcpy(uright, h + o_ur, sizeof(float) * nl);
+    std::memcpy(depth, h + o_dp, sizeof(float) * nl);
+    return ORBX_OK;
 }
 
 int orbx_debug_trig_range(int trig_mode, uint32_t first_bits, uint32_t count, float* d_cos, float* d_sin, void* stream)
@@ -2185,7 +2212,7 @@ int orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* 
     const LevelGeom& L = ex->geo.lv[level];
     if (dst_stride < L.w) return ORBX_ERR_BAD_ARG;
     HIP_CHECK(hipSetDevice(ex->device));
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     // the device copy is tiled (8 rows x 16 bytes per 128-byte tile, tpr tiles per tile row)
     const size_t bytes = (size_t)((L.h + 7) / 8) * L.tpr * 128;
     std::vector<uint8_t> tiled(bytes);
@@ -2200,7 +2227,7 @@ int orbx_debug_candidates(orbx_extractor* ex, int frame, int level, uint32_t* pa
 {
     if (!ex || !n || frame < 0 || frame >= ex->max_batch || level < 0 || level >= ex->geo.nlevels) return ORBX_ERR_BAD_ARG;
     HIP_CHECK(hipSetDevice(ex->device));
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     const Geometry& G = ex->geo;
     const LevelGeom& L = G.lv[level];
     std::vector<uint16_t> cnt(L.cell_count);
@@ -2223,7 +2250,7 @@ int orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, uint32_
 {
     if (!ex || !n || frame < 0 || frame >= ex->max_batch || level < 0 || level >= ex->geo.nlevels) return ORBX_ERR_BAD_ARG;
     HIP_CHECK(hipSetDevice(ex->device));
-    HIP_CHECK(hipStreamSynchronize(ex->stream));
+    HIP_CHECK(sync_context(ex));
     const Geometry& G = ex->geo;
     const LevelGeom& L = G.lv[level];
     int32_t cnt = 0;
@@ -2249,6 +2276,7 @@ int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, in
     if (nIni <= 0 || nIni > kMaxRoots || W >= 4096 || H >= 4096) { set_error("orbx_distribute_octree: unsupported box"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     const float hX = (float)W / nIni;
     const int NC = std::max(std::max(N + 3, 4 * nIni) + 9, 64);
+    if (NC >= 65535) { set_error("orbx_distribute_octree: N of 65523 or more overflows the 16-bit node ids"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     int KL = key_storage == 0 ? 4096 : 0;
     size_t lds = ot_lds_bytes(NC, kOctThreads, KL);
     const bool in_device_memory = lds > 150 * 1024;       // node tables beyond LDS
