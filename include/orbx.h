@@ -268,6 +268,22 @@ int orbx_search_by_projection_lastframe(orbx_matcher* m,
                                         float minX, float maxX, float minY, float maxY,
                                         int mode, int th_dist, int check_ori, const uint8_t* q_transient, int32_t* claimed, int* nmatches);
 
+/* Both searches above for a batch of calls, everything on the device and no host round trip (one wavefront per call:
+ * the frame's features are bucketed by grid cell in LDS, the queries are walked in order, candidates, distances, the
+ * claim step, ratio test / rotation histogram all happen there).  form 0: the last-frame / relocalisation search
+ * (mode, th_dist, check_ori as above); form 1: the map-point search (nnratio).  Call c reads its queries at c * qcap
+ * (d_nq[c] of them; d_qur may be null when d_uright2 is, d_qangle when check_ori is 0, d_q_transient always) and its
+ * frame at c * cap (d_n2[c] features; d_uright2 may be null), and updates d_claimed[c * cap ..] in place as the host
+ * forms do; d_nmatches[c] receives the count.  ORBX_ERR_CAPACITY when 57 * cap + 3 * qcap bytes exceed ~135 KB of LDS
+ * (cap about 2400).  Runs on `stream`; nothing is allocated. */
+int orbx_search_by_projection_batch_device(orbx_matcher* m, int form,
+                                           const float* d_qu, const float* d_qv, const float* d_qradius, const float* d_qur,
+                                           const int32_t* d_qlevel, const float* d_qangle, const uint8_t* d_qdesc, const uint8_t* d_q_transient,
+                                           const int32_t* d_nq, int qcap,
+                                           const orbx_keypoint* d_k2, const uint8_t* d_d2, const float* d_uright2, const int32_t* d_n2, int cap,
+                                           int n_calls, float minX, float maxX, float minY, float maxY, int mode, int th_dist, float nnratio,
+                                           int check_ori, int32_t* d_claimed, int32_t* d_nmatches, void* stream);
+
 /* ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>& vpMatched, th),
  * candidate loop and acceptance (src/ORBmatcher.cc:362-401).  Query i = one projected map point that passed the
  * reference's visibility tests: projection (qu,qv), radius th*scale[level] (:363), predicted level, descriptor.

@@ -277,6 +277,78 @@ def test_search_by_projection_variants(vsa, oracle, matcher, motion_features):
     assert g[1] == o[1] and np.array_equal(g[0], o[0]) and (o[0] <= -2).any()
 
 
+def test_search_by_projection_batch_device(vsa, oracle, matcher, motion_features, stereo_features):
+    """The projection searches for a batch of calls on the device, against the oracle's sequential routines call by call:
+    every motion mode, both acceptance distances, with and without the orientation check, stereo right coordinates,
+    pre-claimed features, queries without observations (overwrites), repeated queries (ties: the visiting order decides),
+    queries outside the image, an empty query list and an empty frame."""
+    import torch
+    w, h, kl, dl, kr, dr = motion_features
+    rng = np.random.default_rng(19)
+    scale = vsa.scale_tables(vsa.make_params())["scale"]
+    bounds = (0.0, float(w), 0.0, float(h))
+    C = 16                                                        # calls in the batch
+    cap = len(kr) + 7; qcap = len(kl) + len(kl) // 3 + 5
+    calls = []
+    for c in range(C):
+        n2 = len(kr) if c != 3 else 0
+        sel = np.concatenate([np.arange(len(kl)), np.arange(0, len(kl), 3)]) if c % 2 else rng.permutation(len(kl))[:max(1, len(kl) // (1 + c % 4))]
+        if c == 5:
+            sel = sel[:0]
+        nq = len(sel)
+        qu = (kl["x"][sel] + 5.0 + rng.uniform(-3, 3, nq)).astype(np.float32); qv = (kl["y"][sel] + 3.0 + rng.uniform(-3, 3, nq)).astype(np.float32)
+        if nq > 10:
+            qu[:3] = [-500.0, 5000.0, 10.0]; qv[:3] = [20.0, 30.0, -900.0]            # windows outside the grid
+        lvl = kl["octave"][sel].astype(np.int32)
+        rad = (rng.choice([7.0, 15.0, 30.0]) * scale[lvl]).astype(np.float32)
+        calls.append(dict(n2=n2, nq=nq, qu=qu, qv=qv, rad=rad, qur=(qu - 5.0).astype(np.float32), lvl=lvl, ang=kl["angle"][sel].astype(np.float32),
+                          qd=dl[sel], tr=(rng.random(nq) < (0.5 if c % 3 == 0 else 0.0)).astype(np.uint8),
+                          ur2=np.where(rng.random(len(kr)) < 0.5, kr["x"] - 5.0, -1.0).astype(np.float32),
+                          cl=np.where(rng.random(len(kr)) < 0.08, 1 << 30, -1).astype(np.int32)))
+    def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    def pack(key, width, dtype, fill=0):
+        out = np.full((C, width) + calls[0][key].shape[1:], fill, dtype)
+        for c, d in enumerate(calls):
+            out[c, :len(d[key])] = d[key]
+        return out
+    d_qu, d_qv, d_rad, d_qur = dev(pack("qu", qcap, np.float32)), dev(pack("qv", qcap, np.float32)), dev(pack("rad", qcap, np.float32)), dev(pack("qur", qcap, np.float32))
+    d_lvl, d_ang, d_qd, d_tr = dev(pack("lvl", qcap, np.int32)), dev(pack("ang", qcap, np.float32)), dev(pack("qd", qcap, np.uint8)), dev(pack("tr", qcap, np.uint8))
+    d_nq = dev(np.array([d["nq"] for d in calls], np.int32)); d_n2 = dev(np.array([d["n2"] for d in calls], np.int32))
+    k2 = np.zeros((C, cap), vsa.KEYPOINT_DTYPE); k2[:, :len(kr)] = kr
+    dd2 = np.zeros((C, cap, 32), np.uint8); dd2[:, :len(kr)] = dr
+    d_k2, d_d2, d_ur2 = dev(k2.view(np.float32).reshape(C, cap, 7)), dev(dd2), dev(pack("ur2", cap, np.float32, -1.0))
+    st = torch.cuda.current_stream().cuda_stream
+    seen_overwrite = False
+    for form, mode, th_dist, ratio, ori, stereo in ((0, 0, 100, 0.0, True, True), (0, 1, 100, 0.0, True, False), (0, 2, 64, 0.0, False, True),
+                                                    (0, 0, 64, 0.0, True, False), (1, 0, 0, 0.8, False, True), (1, 0, 0, 0.6, False, False)):
+        d_cl = dev(pack("cl", cap, np.int32, -1)); d_nm = torch.zeros(C, dtype=torch.int32, device="cuda")
+        matcher.search_by_projection_batch_device(form, d_qu.data_ptr(), d_qv.data_ptr(), d_rad.data_ptr(), d_qur.data_ptr(), d_lvl.data_ptr(),
+                                                  d_ang.data_ptr(), d_qd.data_ptr(), d_tr.data_ptr(), d_nq.data_ptr(), qcap, d_k2.data_ptr(), d_d2.data_ptr(),
+                                                  d_ur2.data_ptr() if stereo else None, d_n2.data_ptr(), cap, C, bounds, mode, th_dist, ratio, ori,
+                                                  d_cl.data_ptr(), d_nm.data_ptr(), st)
+        torch.cuda.synchronize()
+        gcl, gnm = d_cl.cpu().numpy(), d_nm.cpu().numpy()
+        for c, d in enumerate(calls):
+            n2 = d["n2"]
+            ur = d["ur2"][:n2] if stereo else None
+            if form == 0:
+                ocl, on = oracle.search_by_projection_lastframe(d["qu"], d["qv"], d["rad"], d["qur"], d["lvl"], d["ang"], d["qd"], kr[:n2], dr[:n2], ur, bounds,
+                                                                mode, th_dist, ori, d["cl"][:n2], d["tr"]) if d["nq"] and n2 else (d["cl"][:n2], 0)
+            else:
+                ocl, on = oracle.search_by_projection_mappoints(d["qu"], d["qv"], d["rad"], d["qur"], d["lvl"], d["qd"], kr[:n2], dr[:n2], ur, bounds,
+                                                                ratio, d["cl"][:n2], d["tr"]) if d["nq"] and n2 else (d["cl"][:n2], 0)
+            assert gnm[c] == on, (form, mode, c, gnm[c], on)
+            assert np.array_equal(gcl[c, :n2], ocl), (form, mode, c, int(np.count_nonzero(gcl[c, :n2] != ocl)))
+            assert np.array_equal(gcl[c, n2:], pack("cl", cap, np.int32, -1)[c, n2:])
+            seen_overwrite |= on > np.count_nonzero((ocl != -1) & (ocl != (1 << 30)))
+    assert seen_overwrite
+    with pytest.raises(vsa.OrbxError) as e:
+        matcher.search_by_projection_batch_device(0, d_qu.data_ptr(), d_qv.data_ptr(), d_rad.data_ptr(), None, d_lvl.data_ptr(), d_ang.data_ptr(), d_qd.data_ptr(),
+                                                  None, d_nq.data_ptr(), qcap, d_k2.data_ptr(), d_d2.data_ptr(), None, d_n2.data_ptr(), 4000, C, bounds, 0, 100, 0.0,
+                                                  True, d_cl.data_ptr(), d_nm.data_ptr(), st)
+    assert e.value.status == 4
+
+
 def test_stereo_match(vsa, oracle, matcher, stereo_features):
     w, h, kl, dl, kr, dr = stereo_features
     scale = vsa.scale_tables(vsa.make_params())["scale"]

@@ -105,6 +105,7 @@ _SIGS = {
     "orbx_grid_features_in_area": (_i, [_vp, _f, _f, _f, _i, _i, _vp, _i, C.POINTER(_i)]),
     "orbx_search_for_initialization": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _i, _f, _i, _vp, C.POINTER(_i)]),
     "orbx_search_for_initialization_batch_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _i, _f, _i, _vp, _vp, _vp]),
+    "orbx_search_by_projection_batch_device": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _i, _i, _f, _i, _vp, _vp, _vp]),
     "orbx_search_by_projection_mappoints": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, C.POINTER(_i)]),
     "orbx_search_by_projection_lastframe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "orbx_stereo_match": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _f, _f, _vp, _vp]),
@@ -517,6 +518,14 @@ class Matcher:
         _check(lib.orbx_search_for_initialization_batch_device(self.h, d_k1, d_d1, d_n1, d_k2, d_d2, d_n2, cap, n_pairs, bounds[0], bounds[1],
                                                                bounds[2], bounds[3], d_prev, window, nnratio, int(check_ori), d_matches12,
                                                                d_nmatches, stream))
+
+    def search_by_projection_batch_device(self, form, d_qu, d_qv, d_qr, d_qur, d_qlevel, d_qangle, d_qdesc, d_qtransient, d_nq, qcap,
+                                          d_k2, d_d2, d_uright2, d_n2, cap, n_calls, bounds, mode, th_dist, nnratio, check_ori, d_claimed,
+                                          d_nmatches, stream):
+        """All arguments starting with d_ are device pointers (ints; None for the optional ones)."""
+        _check(lib.orbx_search_by_projection_batch_device(self.h, form, d_qu, d_qv, d_qr, d_qur, d_qlevel, d_qangle, d_qdesc, d_qtransient, d_nq,
+                                                          qcap, d_k2, d_d2, d_uright2, d_n2, cap, n_calls, bounds[0], bounds[1], bounds[2],
+                                                          bounds[3], mode, th_dist, nnratio, int(check_ori), d_claimed, d_nmatches, stream))
 
     def search_by_projection_mappoints(self, qu, qv, qr, qur, qlevel, qdesc, k2, d2, uright2, bounds, nnratio, claimed, transient=None):
         transient = None if transient is None else np.ascontiguousarray(transient, np.uint8)

@@ -425,20 +425,41 @@ __device__ __forceinline__ int rotation_bin_dev(float a1, float a2)      // :476
     return bin;
 }
 
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+// inclusive prefix sum over the 64 lanes (all active): DPP shifts inside rows of 16, then the row totals
+__device__ __forceinline__ int wave_scan_incl_i32(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_xor(v, d, 64);
-        v = o < v ? o : v;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
     return v;
 }
-__device__ __forceinline__ int wave_min_i32(int v)
+
+// minimum over the 64 lanes (all active) as a wave-uniform value: the prefix pattern of the sum above with min, whose
+// last lane then holds the minimum of all (six DPP steps instead of six LDS round trips through ds_bpermute)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
-    return v;
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)~0u, (int)v, 0x111, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)~0u, (int)v, 0x112, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)~0u, (int)v, 0x114, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)~0u, (int)v, 0x118, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)~0u, (int)v, 0x142, 0xA, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)~0u, (int)v, 0x143, 0xC, 0xF, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit keys: the high words first, then the low words of the lanes that hold the smallest high word
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mh = wave_min_u32(hi);
+    const uint32_t ml = wave_min_u32(hi == mh ? lo : ~0u);
+    return ((unsigned long long)mh << 32) | ml;
+}
+__device__ __forceinline__ int wave_min_i32(int v)          // values >= 0 only
+{
+    return (int)wave_min_u32((uint32_t)v);
 }
 
 __global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restrict__ k1, const uint32_t* __restrict__ d1, const int32_t* __restrict__ n1v,
@@ -542,7 +563,7 @@ __global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restri
         const int bestDist2 = wave_min_i32(mine);
         const int bestDist = (int)(wbest >> 32);
         if (bestDist <= kThLow && (float)bestDist < __fmul_rn((float)bestDist2, nnratio)) {       // :462-464
-            const int wj = __builtin_amdgcn_readfirstlane(__shfl(bestj, __ffsll((long long)__ballot(winner)) - 1, 64));
+            const int wj = __builtin_amdgcn_readlane(bestj, __ffsll((long long)__ballot(winner)) - 1);
             const int i2 = (int)(s_okey[wj] & 0xFFFFFu);
             if (lane == 0) {
                 const int prev = s_m21[wj];
@@ -579,6 +600,230 @@ __global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restri
         count += __popcll(__ballot(mt >= 0));
     }
     for (int i = n1 + lane; i < cap; i += 64) matches12[i] = -1;
+    if (lane == 0) nmatches[pair] = count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The projection searches of ORBmatcher for a batch of (frame, query list) calls, every step on the device: one
+// wavefront per call.  FORM 0: SearchByProjection(Frame&, const Frame&, th, bMono) and the relocalisation form
+// (src/ORBmatcher.cc:1381-1470, :1531-1598: best-1 within th_dist, rotation histogram).  FORM 1: SearchByProjection(Frame&,
+// const vector<MapPoint*>&, th) (:68-125: best and second best with their levels, ratio test when the levels agree).
+// The frame's features that lie in the 64 x 48 grid are bucketed by grid cell into LDS (counting sort; cells column by
+// column, as Frame::mGrid is walked), each with descriptor, position, octave, angle, right coordinate, claim state and a
+// visiting-order key (column, row, index: the order Frame::GetFeaturesInArea returns candidates in, which the strict `<`
+// of the best-candidate loops turns into the tie-break).  The queries are walked IN ORDER (a claim changes what later
+// queries may take); per query the cells its window covers (src/Frame.cc:332-346) form one run of LDS entries per grid
+// column, the runs are flattened over the 64 lanes, and the best (and second best) candidate is the wave minimum of
+// distance << 32 | visiting order.  A query whose map point has no observations (q_transient) does not block the
+// feature it takes (:87-89, :1406-1408): its claim is stored as -2 - query.
+// ---------------------------------------------------------------------------------------------
+constexpr int kThHigh = 100;
+
+template <int FORM>
+__global__ __launch_bounds__(64) void k_proj_match(const float* __restrict__ qu, const float* __restrict__ qv, const float* __restrict__ qradius,
+                                                   const float* __restrict__ qur, const int32_t* __restrict__ qlevel, const float* __restrict__ qangle,
+                                                   const uint32_t* __restrict__ qdesc, const uint8_t* __restrict__ qtransient,
+                                                   const int32_t* __restrict__ nqv, int qcap,
+                                                   const orbx_keypoint* __restrict__ k2, const uint32_t* __restrict__ d2, const float* __restrict__ uright2,
+                                                   const int32_t* __restrict__ n2v, int cap,
+                                                   float minX, float minY, float invW, float invH, int mode, int th_dist, float nnratio, int check_ori,
+                                                   int32_t* __restrict__ claimed, int32_t* __restrict__ nmatches)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4* s_desc = reinterpret_cast<uint4*>(smem);                                  // 2 x uint4 per entry
+    float2* s_xy = reinterpret_cast<float2*>(smem + (size_t)cap * 32);
+    uint32_t* s_okey = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 40);         // column << 26 | row << 20 | index
+    float* s_angle = reinterpret_cast<float*>(smem + (size_t)cap * 44);
+    float* s_ur = reinterpret_cast<float*>(smem + (size_t)cap * 48);
+    int32_t* s_claim = reinterpret_cast<int32_t*>(smem + (size_t)cap * 52);
+    uint8_t* s_oct = smem + (size_t)cap * 56;
+    const size_t o_cells = ((size_t)cap * 57 + 15) & ~(size_t)15;
+    int32_t* s_cell = reinterpret_cast<int32_t*>(smem + o_cells);                    // [3073] first entry of every cell, column-major
+    uint16_t* s_hj = reinterpret_cast<uint16_t*>(smem + o_cells + 3080 * 4);         // accepted matches: entry ...
+    uint8_t* s_hb = smem + o_cells + 3080 * 4 + (size_t)qcap * 2;                    // ... and histogram bin
+    __shared__ int s_hist[kHistoLength];
+    __shared__ int s_run_b[64], s_run_i[64];                                         // per grid column of a window: first entry, inclusive length prefix
+
+    const int lane = threadIdx.x;
+    const int pair = blockIdx.x;
+    const size_t foff = (size_t)pair * cap, qoff = (size_t)pair * qcap;
+    k2 += foff; d2 += foff * 8; claimed += foff; if (uright2) uright2 += foff;
+    qu += qoff; qv += qoff; qradius += qoff; qlevel += qoff; qdesc += qoff * 8;
+    if (qur) qur += qoff; if (qangle) qangle += qoff; if (qtransient) qtransient += qoff;
+    const int n2 = min(n2v[pair], cap), nq = min(nqv[pair], qcap);
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
+    auto cell_of = [&](const orbx_keypoint& kp, int& px, int& py) -> bool {         // Frame::PosInGrid, src/Frame.cc:382-392
+        px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, minX), invW));
+        py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, minY), invH));
+        return px >= 0 && px < 64 && py >= 0 && py < 48;
+    };
+
+    // counting sort of the in-grid features by cell: counts, exclusive prefix (lane c owns grid column c), placement
+    for (int i = lane; i < 3073; i += 64) s_cell[i] = 0;
+    if (lane < kHistoLength) s_hist[lane] = 0;
+    wsync();
+    for (int j = lane; j < n2; j += 64) {
+        int px, py;
+        if (cell_of(k2[j], px, py)) atomicAdd(&s_cell[px * 48 + py], 1);
+    }
+    wsync();
+    {
+        int sum = 0;
+        for (int r = 0; r < 48; ++r) sum += s_cell[lane * 48 + r];
+        int run = wave_scan_incl_i32(sum) - sum;
+        for (int r = 0; r < 48; ++r) { const int c = s_cell[lane * 48 + r]; s_cell[lane * 48 + r] = run; run += c; }
+        if (lane == 63) s_cell[3072] = run;
+    }
+    wsync();
+    for (int j0 = 0; j0 < n2; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < n2) {
+            const orbx_keypoint kp = k2[j];
+            int px, py;
+            if (cell_of(kp, px, py)) {
+                const int pos = atomicAdd(&s_cell[px * 48 + py], 1);               // the cell's cursor; the starts are restored below
+                const uint4* tp = reinterpret_cast<const uint4*>(d2 + (size_t)j * 8);
+                s_desc[2 * pos] = tp[0]; s_desc[2 * pos + 1] = tp[1];
+                s_xy[pos] = make_float2(kp.x, kp.y);
+                s_okey[pos] = ((uint32_t)px << 26) | ((uint32_t)py << 20) | (uint32_t)j;
+                s_angle[pos] = kp.angle;
+                s_ur[pos] = uright2 ? uright2[j] : -1.0f;
+                s_claim[pos] = claimed[j];
+                s_oct[pos] = (uint8_t)kp.octave;
+            }
+        }
+    }
+    wsync();
+    // after the placement cell c's counter holds the start of cell c + 1: shift back by one cell
+    {
+        int v[48];
+#pragma unroll
+        for (int r = 0; r < 48; ++r) { const int i = lane * 48 + r; v[r] = i == 0 ? 0 : s_cell[i - 1]; }
+        wsync();
+#pragma unroll
+        for (int r = 0; r < 48; ++r) s_cell[lane * 48 + r] = v[r];
+    }
+    wsync();
+
+    int count = 0, nacc = 0;
+    uint32_t nd[8]; float nu = 0.f, nv = 0.f, nr = -1.f, nur = 0.f, nang = 0.f; int nlev = 0, ntr = 0;
+    auto fetch = [&](int e) {
+        if (e < nq) {
+            const uint4* tp = reinterpret_cast<const uint4*>(qdesc + (size_t)e * 8);
+            const uint4 lo = tp[0], hi = tp[1];
+            nd[0] = lo.x; nd[1] = lo.y; nd[2] = lo.z; nd[3] = lo.w; nd[4] = hi.x; nd[5] = hi.y; nd[6] = hi.z; nd[7] = hi.w;
+            nu = qu[e]; nv = qv[e]; nr = qradius[e]; nlev = qlevel[e];
+            nur = qur ? qur[e] : 0.f; nang = qangle ? qangle[e] : 0.f; ntr = qtransient ? qtransient[e] : 0;
+        }
+    };
+    fetch(0);
+    for (int e = 0; e < nq; ++e) {
+        uint32_t cd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cd[k] = nd[k];
+        const float u = nu, v = nv, r = nr, ur = nur, ang = nang; const int lev = nlev, transient = ntr;
+        fetch(e + 1);
+        // level band of the window (src/Frame.cc:348, :357-363)
+        int minLevel, maxLevel;
+        if (FORM == 1) { minLevel = lev - 1; maxLevel = lev; }
+        else if (mode == 1) { minLevel = lev; maxLevel = -1; }
+        else if (mode == 2) { minLevel = 0; maxLevel = lev; }
+        else { minLevel = lev - 1; maxLevel = lev + 1; }
+        const bool checkLevels = minLevel > 0 || maxLevel >= 0;
+        // cells the window covers (src/Frame.cc:332-346)
+        const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(u, minX), r), invW)));
+        const int cx1 = min(63, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, minX), r), invW)));
+        const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, minY), r), invH)));
+        const int cy1 = min(47, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(v, minY), r), invH)));
+        if (!(r >= 0.0f) || cx0 >= 64 || cx1 < 0 || cy0 >= 48 || cy1 < 0 || cx1 < cx0 || cy1 < cy0) continue;
+        // one run of entries per covered grid column; inclusive prefix of the run lengths
+        const int ncols = cx1 - cx0 + 1;
+        int rb = 0, rl = 0;
+        if (lane < ncols) { rb = s_cell[(cx0 + lane) * 48 + cy0]; rl = s_cell[(cx0 + lane) * 48 + cy1 + 1] - rb; }
+        const int incl = wave_scan_incl_i32(rl);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0) continue;
+        s_run_b[lane] = rb - (incl - rl);                                  // entry = s_run_b[column] + t for t in the column's span
+        s_run_i[lane] = incl;
+        wsync();
+        unsigned long long best = ~0ull, second = ~0ull;                   // distance << 32 | visiting order
+        int bestj = -1, secondj = -1;
+        for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            if (t >= total) continue;
+            int c = 0;                                                     // first column whose inclusive prefix exceeds t
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) if (c + step <= ncols && s_run_i[c + step - 1] <= t) c += step;
+            const int j = s_run_b[c] + t;
+            const int oct = s_oct[j];
+            if (checkLevels && (oct < minLevel || (maxLevel >= 0 && oct > maxLevel))) continue;
+            const float2 p = s_xy[j];
+            if (!(fabsf(__fsub_rn(p.x, u)) < r && fabsf(__fsub_rn(p.y, v)) < r)) continue;       // src/Frame.cc:370-374
+            if (s_claim[j] >= 0) continue;                                                      // :87-89, :1406-1408, :1544-1545
+            const float urj = s_ur[j];
+            if (urj > 0.0f && fabsf(__fsub_rn(ur, urj)) > r) continue;                           // :91-96, :1410-1416
+            const uint4 lo = s_desc[2 * j], hi = s_desc[2 * j + 1];
+            const int dist = __popc(cd[0] ^ lo.x) + __popc(cd[1] ^ lo.y) + __popc(cd[2] ^ lo.z) + __popc(cd[3] ^ lo.w) +
+                             __popc(cd[4] ^ hi.x) + __popc(cd[5] ^ hi.y) + __popc(cd[6] ^ hi.z) + __popc(cd[7] ^ hi.w);
+            const unsigned long long key = ((unsigned long long)(uint32_t)dist << 32) | s_okey[j];
+            if (key < best) { second = best; secondj = bestj; best = key; bestj = j; }
+            else if (key < second) { second = key; secondj = j; }
+        }
+        const unsigned long long wbest = wave_min_u64(best);
+        if (wbest == ~0ull) continue;
+        const bool winner = best == wbest;
+        const int wlane = __ffsll((long long)__ballot(winner)) - 1;
+        const int wj = __builtin_amdgcn_readlane(bestj, wlane);
+        const int bestDist = (int)(wbest >> 32);
+        bool accept;
+        if (FORM == 0) accept = bestDist <= th_dist;                       // :1428, :1556
+        else {
+            // second best in visiting order among equal distances = the second smallest key (:100-113)
+            const unsigned long long mine = winner ? second : best;
+            const unsigned long long wsecond = wave_min_u64(mine);
+            accept = bestDist <= kThHigh;                                  // :116
+            if (accept && wsecond != ~0ull) {
+                const bool w2 = mine == wsecond;
+                const int l2 = __ffsll((long long)__ballot(w2)) - 1;
+                const int sj = __builtin_amdgcn_readlane(winner ? secondj : bestj, l2);
+                const int bestDist2 = (int)(wsecond >> 32);
+                if (s_oct[wj] == s_oct[sj] && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) accept = false;     // :118-119
+            }
+        }
+        if (accept) {
+            if (lane == 0) {
+                s_claim[wj] = transient ? -2 - e : e;                       // :123, :1431
+                if (FORM == 0 && check_ori) {
+                    const int bin = rotation_bin_dev(ang, s_angle[wj]);    // :1436-1444
+                    s_hj[nacc] = (uint16_t)wj; s_hb[nacc] = (uint8_t)bin; ++s_hist[bin];
+                }
+            }
+            ++nacc; ++count;
+            wsync();
+        }
+    }
+    wsync();
+    if (FORM == 0 && check_ori) {                                          // :1449-1470
+        int ind1 = -1, ind2 = -1, ind3 = -1, m1 = 0, m2 = 0, m3 = 0;
+        for (int i = 0; i < kHistoLength; ++i) {
+            const int sz = s_hist[i];
+            if (sz > m1) { m3 = m2; m2 = m1; m1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > m2) { m3 = m2; m2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > m3) { m3 = sz; ind3 = i; }
+        }
+        if ((float)m2 < __fmul_rn(0.1f, (float)m1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)m3 < __fmul_rn(0.1f, (float)m1)) ind3 = -1;
+        for (int a0 = 0; a0 < nacc; a0 += 64) {
+            const int a = a0 + lane;
+            bool drop = false;
+            if (a < nacc) { const int bin = s_hb[a]; drop = bin != ind1 && bin != ind2 && bin != ind3; }
+            if (drop) s_claim[s_hj[a]] = -1;                               // every entry of a rejected bin clears its slot and counts down
+            count -= __popcll(__ballot(drop));
+        }
+        wsync();
+    }
+    const int nin = s_cell[3072];
+    for (int j = lane; j < nin; j += 64) claimed[s_okey[j] & 0xFFFFFu] = s_claim[j];
     if (lane == 0) nmatches[pair] = count;
 }
 
@@ -829,6 +1074,42 @@ int orbx_search_for_initialization_batch_device(orbx_matcher* m, const orbx_keyp
     hipLaunchKernelGGL(k_init_match, dim3(n_pairs), dim3(64), lds, (hipStream_t)stream, d_k1, reinterpret_cast<const uint32_t*>(d_d1), d_n1,
                        d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_n2, cap, minX, minY, invW, invH, d_prev_matched_xy, (float)window, nnratio,
                        check_ori, d_matches12, d_nmatches);
+    HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_search_by_projection_batch_device(orbx_matcher* m, int form,
+                                           const float* d_qu, const float* d_qv, const float* d_qradius, const float* d_qur,
+                                           const int32_t* d_qlevel, const float* d_qangle, const uint8_t* d_qdesc, const uint8_t* d_q_transient,
+                                           const int32_t* d_nq, int qcap,
+                                           const orbx_keypoint* d_k2, const uint8_t* d_d2, const float* d_uright2, const int32_t* d_n2, int cap,
+                                           int n_calls, float minX, float maxX, float minY, float maxY, int mode, int th_dist, float nnratio,
+                                           int check_ori, int32_t* d_claimed, int32_t* d_nmatches, void* stream)
+{
+    if (!m || form < 0 || form > 1 || cap < 1 || qcap < 1 || n_calls < 0 || !(maxX > minX) || !(maxY > minY) || mode < 0 || mode > 2) {
+        set_error("orbx_search_by_projection_batch_device: bad argument"); return ORBX_ERR_BAD_ARG;
+    }
+    if (n_calls == 0) return ORBX_OK;
+    if (!d_qu || !d_qv || !d_qradius || !d_qlevel || !d_qdesc || !d_nq || !d_k2 || !d_d2 || !d_n2 || !d_claimed || !d_nmatches ||
+        (d_uright2 && !d_qur) || (form == 0 && check_ori && !d_qangle)) {
+        set_error("orbx_search_by_projection_batch_device: null pointer"); return ORBX_ERR_BAD_ARG;
+    }
+    const size_t lds = (((size_t)cap * 57 + 15) & ~(size_t)15) + 3080 * 4 + (size_t)qcap * 3 + 16;
+    if (lds > 150 * 1024 || cap >= (1 << 16) || qcap >= (1 << 20)) {
+        set_error("orbx_search_by_projection_batch_device: frame capacity (57 bytes per feature) plus 3 bytes per query do not fit the LDS of one CU"); return ORBX_ERR_CAPACITY;
+    }
+    HIP_CHECK(hipSetDevice(m->device));
+    const float invW = 64.0f / (maxX - minX), invH = 48.0f / (maxY - minY);      // src/Frame.cc:101-102
+    const void* fn = form == 0 ? reinterpret_cast<const void*>(k_proj_match<0>) : reinterpret_cast<const void*>(k_proj_match<1>);
+    HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (form == 0)
+        hipLaunchKernelGGL(k_proj_match<0>, dim3(n_calls), dim3(64), lds, (hipStream_t)stream, d_qu, d_qv, d_qradius, d_qur, d_qlevel, d_qangle,
+                           reinterpret_cast<const uint32_t*>(d_qdesc), d_q_transient, d_nq, qcap, d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_uright2,
+                           d_n2, cap, minX, minY, invW, invH, mode, th_dist, nnratio, check_ori, d_claimed, d_nmatches);
+    else
+        hipLaunchKernelGGL(k_proj_match<1>, dim3(n_calls), dim3(64), lds, (hipStream_t)stream, d_qu, d_qv, d_qradius, d_qur, d_qlevel, d_qangle,
+                           reinterpret_cast<const uint32_t*>(d_qdesc), d_q_transient, d_nq, qcap, d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_uright2,
+                           d_n2, cap, minX, minY, invW, invH, mode, th_dist, nnratio, check_ori, d_claimed, d_nmatches);
     HIP_CHECK(hipGetLastError());
     return ORBX_OK;
 }
