@@ -1,5 +1,6 @@
 // Single-thread host build of the level-synchronous quadtree (octree_algo.h) for CPU unit tests:
 // the HIP kernel runs the same source with one workgroup per (frame, level).
+// table_cap: capacity of the count tables (0: every sweep walks the keys; -1: what the library would give this level).
 #define ORBX_OCTREE_HOST_SIM 1
 #include "../../visual-slam_amd/csrc/octree_algo.h"
 #include <vector>
@@ -7,7 +8,7 @@
 using namespace orbx;
 
 extern "C" int otsim_distribute(const uint32_t* keys, int nk, int minX, int maxX, int minY, int maxY, int N,
-                                uint32_t* out, int cap)
+                                uint32_t* out, int cap, int table_cap)
 {
     const int W = maxX - minX, H = maxY - minY;
     const int nIni = (int)std::round((float)W / H);
@@ -17,8 +18,18 @@ extern "C" int otsim_distribute(const uint32_t* keys, int nk, int minX, int maxX
     std::vector<OtNode> a(NC), b(NC);
     std::vector<int32_t> cc(4 * NC), candPos(NC), pi(NC), cByPi(NC), keep(NC), posToCand(NC), cc2(2 * NC + 2), scal(16), tmp(8);
     std::vector<uint16_t> nodeOf(nk > 0 ? nk : 1);
-    OtShared s{a.data(), b.data(), cc.data(), candPos.data(), pi.data(), cByPi.data(), keep.data(), posToCand.data(), reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(cc2.data()) + 7) & ~(uintptr_t)7), scal.data(), tmp.data()};
+    const int TC = table_cap < 0 ? ot_table_size(nIni, ot_table_depth(N, nIni, 4096)) : table_cap;
+    std::vector<int32_t> tcnt(TC + 1);
+    std::vector<uint16_t> tpos(TC + 1);
+    OtShared s{a.data(), b.data(), cc.data(), candPos.data(), pi.data(), cByPi.data(), keep.data(), posToCand.data(), reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(cc2.data()) + 7) & ~(uintptr_t)7), scal.data(), tmp.data(),
+               tcnt.data(), tpos.data(), TC};
     OtMemKeys ks{keys, nodeOf.data(), nk};
     (void)W;
     return ot_distribute(s, ks, keys, H, nIni, hX, N, out, cap);
+}
+
+extern "C" void otsim_sweeps(int* on_tables, int* on_keys, int reset)
+{
+    *on_tables = ot_sim_sweeps[0]; *on_keys = ot_sim_sweeps[1];
+    if (reset) ot_sim_sweeps[0] = ot_sim_sweeps[1] = 0;
 }

@@ -227,6 +227,28 @@ def oracle_level(oracle, img, l):
     return oex.level_padded(l)
 
 
+def test_octree_count_tables(vsa, oracle):
+    """Key sets large enough (32 keys per thread and more) for the coarse sweeps to run on the count tables, spread out
+    and clustered (clusters make the sweeps outlast the tables' depth)."""
+    rng = np.random.default_rng(23)
+    for it, (W, H, n, N) in enumerate([(1200, 400, 30000, 300), (1200, 400, 60000, 1500), (608, 448, 20000, 217), (2000, 900, 50000, 4000),
+                                       (3808, 2128, 90000, 434), (900, 450, 25000, 40), (1200, 400, 30000, 0)]):
+        xs = rng.integers(3, W - 3, n); ys = rng.integers(3, H - 3, n)
+        if it % 2:
+            k = n // 2
+            xs[:k] = np.clip(W // 3 + rng.integers(-60, 61, k), 3, W - 4); ys[:k] = np.clip(H // 2 + rng.integers(-60, 61, k), 3, H - 4)
+        pts = sorted(set((int(y) // 32, int(x) // 31, int(y), int(x)) for x, y in zip(xs, ys)))
+        assert len(pts) >= 32 * 256
+        x = np.array([p[3] for p in pts], np.int16); y = np.array([p[2] for p in pts], np.int16)
+        s = rng.integers(7, 12 if it % 3 == 0 else 200, len(pts)).astype(np.uint8)
+        keys = vsa.pack_keys(x, y, s)
+        sel = oracle.distribute_octree(x, y, s, 16, 16 + W, 16, 16 + H, N)
+        for storage in (0, 1):
+            got = vsa.distribute_octree(keys, 16, 16 + W, 16, 16 + H, N, device=0, key_storage=storage)
+            assert len(got) == len(sel), (it, W, H, len(pts), N, storage)
+            assert np.array_equal(got, keys[sel]), (it, W, H, len(pts), N, storage)
+
+
 def test_octree_standalone_random(vsa, oracle):
     rng = np.random.default_rng(5)
     for it in range(40):

@@ -17,7 +17,7 @@ def load_sim():
         subprocess.check_call(["make", "-C", os.path.join(HERE, "helpers"), "-s", "-B"])
     lib = C.CDLL(path)
     lib.otsim_distribute.restype = C.c_int
-    lib.otsim_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.otsim_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
     return lib
 
 
@@ -25,6 +25,7 @@ def test_parallel_formulation_equals_list_version(oracle, vsa):
     lib = load_sim()
     rng = np.random.default_rng(11)
     checked = 0
+    sweeps = {}
     for it in range(300):
         W, H = int(rng.integers(60, 1300)), int(rng.integers(60, 520))
         if it % 9 == 0:
@@ -50,9 +51,19 @@ def test_parallel_formulation_equals_list_version(oracle, vsa):
         keys = vsa.pack_keys(x, y, s)
         sel = oracle.distribute_octree(x, y, s, 16, 16 + W, 16, 16 + H, N)
         cap = max(N + 3, 4 * round(W / H)) + 1
-        out = np.zeros(cap, np.uint32)
-        m = lib.otsim_distribute(keys.ctypes.data, len(keys), 16, 16 + W, 16, 16 + H, N, out.ctypes.data, cap)
-        assert m == len(sel), (it, W, H, len(pts), N)
-        assert np.array_equal(out[:m], keys[sel]), (it, W, H, len(pts), N)
+        # count tables as the library sizes them, none (every sweep walks the keys), and too small for the full depth
+        for table_cap in (-1, 0, 5 * round(W / H), 90 * round(W / H)):
+            out = np.zeros(cap, np.uint32)
+            m = lib.otsim_distribute(keys.ctypes.data, len(keys), 16, 16 + W, 16, 16 + H, N, out.ctypes.data, cap, table_cap)
+            assert m == len(sel), (it, W, H, len(pts), N, table_cap)
+            assert np.array_equal(out[:m], keys[sel]), (it, W, H, len(pts), N, table_cap)
+            a, b = C.c_int(), C.c_int()
+            lib.otsim_sweeps(C.byref(a), C.byref(b), 1)
+            t = sweeps.setdefault(table_cap if table_cap <= 0 else 1, [0, 0])
+            t[0] += a.value; t[1] += b.value
         checked += 1
     assert checked > 250
+    # the library's table size covers most of the coarse sweeps; without tables every sweep walks the keys
+    assert sweeps[0][0] == 0 and sweeps[-1][0] > 2 * sweeps[-1][1], sweeps
+    assert sweeps[1][0] > 0 and sweeps[1][1] > 0, sweeps
+    print(sweeps)

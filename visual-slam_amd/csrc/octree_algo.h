@@ -19,6 +19,10 @@
 #ifdef ORBX_OCTREE_HOST_SIM
 #include <cmath>
 #define OT_DEV
+// sweeps of the coarse phase by kind (0: on the count tables, 1: walking the keys), for the tests
+static int ot_sim_sweeps[2];
+#define OT_STAT(i) (++ot_sim_sweeps[i])
+#define OT_HD static inline
 #define OT_TID 0
 #define OT_NT 1
 #define OT_SYNC() ((void)0)
@@ -28,6 +32,8 @@ static inline float ot_fdiv(float a, float b) { return a / b; }
 static inline void ot_count(int* base, int idx) { if (idx >= 0) base[idx] += 1; }
 #else
 #define OT_DEV __device__ __forceinline__
+#define OT_STAT(i) ((void)0)
+#define OT_HD static __host__ __device__ inline
 #define OT_TID ((int)threadIdx.x)
 #define OT_NT ((int)blockDim.x)
 #define OT_SYNC() __syncthreads()
@@ -86,8 +92,30 @@ struct OtShared {
     int32_t* cc2;          // [NC*2] 8-byte aligned scratch: 64-bit sort keys of the fine pass
     int32_t* scal;         // [16] scalars
     int32_t* scanTmp;      // [NT/64 + 2] block-scan scratch (device)
+    int32_t* tcnt;         // [tcap] key counts of the full quadtree's cells down to the table depth (see ot_table_depth)
+    uint16_t* tpos;        // [tcap] list position of the node that stands for a cell when the tables are put to use
+    int tcap;              // capacity of the two tables in entries (0: no tables)
 };
 enum { OT_N = 0, OT_E = 1, OT_C = 2, OT_RSTAR = 3, OT_NEXP = 4, OT_SEQ = 5, OT_TMP = 6, OT_NSPLIT = 7 };
+
+// Count tables.  As long as the coarse sweeps run, every node with more than one key is split in every sweep, so after t
+// sweeps those nodes are exactly the non-empty depth-t cells of the full quadtree under the roots, and a key's cell at any
+// depth follows from its coordinates alone.  One pass over the keys therefore counts the cells of the deepest level D;
+// sums give the levels above; the sweeps then work on node records only (their child counts are table look-ups), and one
+// more pass at the end hands every key to its node.  Two passes over the keys instead of two per sweep.
+// Level d (0 = the roots) holds nIni * 4^d cells, cell index = root * 4^d + quadrant path, levels stored back to back.
+constexpr int kOtTableMinKeysPerThread = 32;
+OT_HD int ot_table_size(int nIni, int d) { long long s = 0, c = nIni; for (int i = 0; i <= d; ++i) { s += c; c *= 4; } return s > 0x7FFFFFFF ? 0x7FFFFFFF : (int)s; }
+OT_HD int ot_table_off(int nIni, int d) { return d <= 0 ? 0 : ot_table_size(nIni, d - 1); }
+// Depth of the tables: the first level with at least N cells (the coarse sweeps stop before the list reaches N nodes, so
+// they rarely go deeper; if they do, the remaining sweeps walk the keys as before), as far as the capacity allows.
+OT_HD int ot_table_depth(int N, int nIni, int tcap)
+{
+    int d = 0; long long cells = nIni;
+    while (cells < N && d < 7) { cells *= 4; ++d; }
+    while (d > 0 && ot_table_size(nIni, d) > tcap) --d;
+    return d;
+}
 
 // exclusive prefix sum of a[0..n) in place; returns the total.  All threads call it.
 static OT_DEV int ot_block_scan(int32_t* a, int n, int32_t* tmp)
@@ -156,6 +184,26 @@ static OT_DEV void ot_child_box(const OtNode& p, int q, OtNode& c)
     c.y1 = (int16_t)((q & 2) ? p.y1 : my);
 }
 
+// A key's way down the full quadtree: the box of its cell, refined one level per call exactly as ot_quadrant / ot_child_box do
+struct OtBox { int x0, x1, y0, y1; };
+static OT_DEV void ot_root_box(int r, float hX, int H, OtBox& b)
+{
+    b.x0 = (int16_t)(int)(hX * (float)r); b.x1 = (int16_t)(int)(hX * (float)(r + 1)); b.y0 = 0; b.y1 = (int16_t)H;
+}
+static OT_DEV int ot_key_root(uint32_t key, float hX, int nIni)
+{
+    const int r = (int)ot_fdiv((float)ot_key_x(key), hX);
+    return r > nIni - 1 ? nIni - 1 : r;
+}
+static OT_DEV int ot_descend(OtBox& b, uint32_t key)
+{
+    const int mx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), my = b.y0 + ((b.y1 - b.y0 + 1) >> 1);
+    const int right = ot_key_x(key) >= mx, bottom = ot_key_y(key) >= my;
+    if (right) b.x0 = mx; else b.x1 = mx;
+    if (bottom) b.y0 = my; else b.y1 = my;
+    return right + 2 * bottom;
+}
+
 // Key storage.  Thread tid owns the keys tid, tid+nt, tid+2nt, ... ("slot" j = key tid + j*nt) for the whole
 // run, and only the owner ever touches a key's node id.  The arrays live in LDS when a level's keys fit
 // there and in device memory otherwise.
@@ -203,20 +251,32 @@ static OT_DEV void ot_for_keys4(KS& ks, int tid, int nt, L&& look, C&& commit)
 
 // Coarse sweep (:605-664): every node with more than one key is split, in list order.  One packed prefix sum
 // (children in the low half, unsplit nodes in the high half) places everything.
-template <class KS>
-static OT_DEV void ot_coarse_step(OtShared& s, KS& ks)
+// TABLES: sweep number t of a run on the count tables: pc[p] is the table entry of node p (all nodes with more than one
+// key are depth-t cells), the child counts are look-ups, pn receives the entries of the new list, and no key is touched.
+template <bool TABLES, class KS>
+static OT_DEV void ot_coarse_step(OtShared& s, KS& ks, int t = 0, int nIni = 0, const int32_t* pc = nullptr, int32_t* pn = nullptr)
 {
     const int tid = OT_TID, nt = OT_NT;
     const int n = s.scal[OT_N];
-    for (int i = tid; i < 4 * n; i += nt) s.cc[i] = 0;
-    if (tid == 0) s.scal[OT_NEXP] = 0;
-    OT_SYNC();
-    ot_for_keys4(ks, tid, nt,
-        [&](int j, int k) -> int {
-            const uint16_t p = ks.get(j, k);
-            return p == kOtDead ? -1 : 4 * p + ot_quadrant(s.cur[p], ks.key(j, k));
-        },
-        [&](int, int, int target) { ot_count(s.cc, target); });
+    const int offT = TABLES ? ot_table_off(nIni, t) : 0, offC = TABLES ? ot_table_off(nIni, t + 1) : 0;
+    if (TABLES) {
+        for (int p = tid; p < n; p += nt)
+            if (s.cur[p].cnt > 1) {
+                const int32_t* c = &s.tcnt[offC + 4 * (pc[p] - offT)];
+                s.cc[4 * p] = c[0]; s.cc[4 * p + 1] = c[1]; s.cc[4 * p + 2] = c[2]; s.cc[4 * p + 3] = c[3];
+            }
+        if (tid == 0) s.scal[OT_NEXP] = 0;
+    } else {
+        for (int i = tid; i < 4 * n; i += nt) s.cc[i] = 0;
+        if (tid == 0) s.scal[OT_NEXP] = 0;
+        OT_SYNC();
+        ot_for_keys4(ks, tid, nt,
+            [&](int j, int k) -> int {
+                const uint16_t p = ks.get(j, k);
+                return p == kOtDead ? -1 : 4 * p + ot_quadrant(s.cur[p], ks.key(j, k));
+            },
+            [&](int, int, int target) { ot_count(s.cc, target); });
+    }
     OT_SYNC();
     for (int p = tid; p < n; p += nt) {
         const int* c = &s.cc[4 * p];
@@ -242,6 +302,7 @@ static OT_DEV void ot_coarse_step(OtShared& s, KS& ks)
                     ch.cnt = cnt;
                     ch.aux = (uint32_t)(seqBase + cex + before);
                     s.nxt[np] = ch;
+                    if (TABLES) pn[np] = offC + 4 * (pc[p] - offT) + q;
                     c[q] = cnt == 1 ? np | kOtSingle : np;   // the key of a one-key child is parked in the child
                     nexp += cnt > 1;
                     ++before;
@@ -250,21 +311,55 @@ static OT_DEV void ot_coarse_step(OtShared& s, KS& ks)
             if (nexp) ot_atomic_add(&s.scal[OT_NEXP], nexp);
         } else {
             s.nxt[C + kex] = s.cur[p];       // nodes with one key keep their relative order at the back
+            if (TABLES) pn[C + kex] = pc[p];
         }
     }
     OT_SYNC();
+    if (!TABLES)
+        ot_for_keys4(ks, tid, nt,
+            [&](int j, int k) -> int {
+                const uint16_t p = ks.get(j, k);
+                if (p == kOtDead) return -1;
+                return s.cc[4 * p + ot_quadrant(s.cur[p], ks.key(j, k))];
+            },
+            [&](int j, int k, int np) {
+                if (np < 0) return;
+                if (np & kOtSingle) { s.nxt[np & 0xFFFF].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
+                else ks.set(j, k, (uint16_t)np);
+            });
+    if (tid == 0) { s.scal[OT_N] = C + nkeep; s.scal[OT_SEQ] = seqBase + C; }
+    OT_SYNC();
+}
+
+// End of a run on the count tables after T sweeps: every key goes to its node.  Walking down from its root a key stops at
+// the first cell that holds it alone (that node keeps the key in its record) or at depth T (the nodes still to be split).
+template <class KS>
+static OT_DEV void ot_tables_to_keys(OtShared& s, KS& ks, int T, int nIni, float hX, int H, const int32_t* pc)
+{
+    const int tid = OT_TID, nt = OT_NT;
+    const int n = s.scal[OT_N];
+    for (int p = tid; p < n; p += nt) s.tpos[pc[p]] = (uint16_t)p;
+    OT_SYNC();
     ot_for_keys4(ks, tid, nt,
         [&](int j, int k) -> int {
-            const uint16_t p = ks.get(j, k);
-            if (p == kOtDead) return -1;
-            return s.cc[4 * p + ot_quadrant(s.cur[p], ks.key(j, k))];
+            const uint32_t key = ks.key(j, k);
+            int idx = ot_key_root(key, hX, nIni);
+            OtBox b;
+            ot_root_box(idx, hX, H, b);
+            int off = 0, cells = nIni;
+            for (int d = 0; ; ++d) {
+                const int e = off + idx;
+                if (s.tcnt[e] == 1) return (int)s.tpos[e] | kOtSingle;
+                if (d == T) return (int)s.tpos[e];
+                idx = 4 * idx + ot_descend(b, key);
+                off += cells; cells *= 4;
+            }
         },
         [&](int j, int k, int np) {
             if (np < 0) return;
-            if (np & kOtSingle) { s.nxt[np & 0xFFFF].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
+            if (np & kOtSingle) { s.cur[np & 0xFFFF].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
             else ks.set(j, k, (uint16_t)np);
         });
-    if (tid == 0) { s.scal[OT_N] = C + nkeep; s.scal[OT_SEQ] = seqBase + C; }
     OT_SYNC();
 }
 
@@ -420,6 +515,12 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
                                 int H, int nIni, float hX, int N, uint32_t* out, int outCap)
 {
     const int tid = OT_TID, nt = OT_NT;
+    // the tables pay once a thread has many keys to walk per pass (measured: 88 keys per thread -27 % of the whole
+    // selection, 12 to 20 keys per thread +6 %: zeroing, summing and the deeper walks cost more than the passes saved)
+    const int D = ks.nk >= kOtTableMinKeysPerThread * nt ? ot_table_depth(N, nIni, s.tcap) : 0;
+    int32_t* pc = s.candPos;        // table entries of the nodes of cur / nxt while the sweeps run on the count tables
+    int32_t* pn = s.pi;             // (both arrays are otherwise used by the fine steps only)
+    bool tables = D > 0;
     // roots (:551-569)
     for (int i = tid; i < nIni; i += nt) {
         OtNode r;
@@ -431,41 +532,77 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
         s.cc[i] = 0;
     }
     if (tid == 0) { s.scal[OT_SEQ] = nIni; }
-    OT_SYNC();
-    ot_for_keys4(ks, tid, nt,
-        [&](int j, int k) -> int {
-            int r = (int)ot_fdiv((float)ot_key_x(ks.key(j, k)), hX);
-            return r > nIni - 1 ? nIni - 1 : r;
-        },
-        [&](int j, int k, int r) {
-            if (r >= 0) ks.set(j, k, (uint16_t)r);
-            ot_count(s.cc, r);
-        });
+    if (tables) {
+        const int total = ot_table_size(nIni, D);
+        for (int i = tid; i < total; i += nt) s.tcnt[i] = 0;
+        OT_SYNC();
+        int32_t* deepest = s.tcnt + ot_table_off(nIni, D);
+        ot_for_keys4(ks, tid, nt,
+            [&](int j, int k) -> int {
+                const uint32_t key = ks.key(j, k);
+                int idx = ot_key_root(key, hX, nIni);
+                OtBox b;
+                ot_root_box(idx, hX, H, b);
+                for (int d = 0; d < D; ++d) idx = 4 * idx + ot_descend(b, key);
+                return idx;
+            },
+            [&](int, int, int idx) { ot_count(deepest, idx); });
+        OT_SYNC();
+        for (int d = D - 1; d >= 0; --d) {
+            const int32_t* below = s.tcnt + ot_table_off(nIni, d + 1);
+            int32_t* here = s.tcnt + ot_table_off(nIni, d);
+            const int cells = ot_table_size(nIni, d) - ot_table_off(nIni, d);
+            for (int i = tid; i < cells; i += nt) here[i] = below[4 * i] + below[4 * i + 1] + below[4 * i + 2] + below[4 * i + 3];
+            OT_SYNC();
+        }
+        for (int i = tid; i < nIni; i += nt) s.cc[i] = s.tcnt[i];
+    } else {
+        OT_SYNC();
+        ot_for_keys4(ks, tid, nt,
+            [&](int j, int k) -> int { return ot_key_root(ks.key(j, k), hX, nIni); },
+            [&](int j, int k, int r) {
+                if (r >= 0) ks.set(j, k, (uint16_t)r);
+                ot_count(s.cc, r);
+            });
+    }
     OT_SYNC();
     // drop empty roots (:571-584); a root with one key keeps it
     for (int i = tid; i < nIni; i += nt) { s.nxt[i].cnt = s.cc[i]; s.keep[i] = s.cc[i] > 0 ? 1 : 0; }
     OT_SYNC();
     const int n0 = ot_block_scan(s.keep, nIni, s.scanTmp);
-    for (int i = tid; i < nIni; i += nt) if (s.nxt[i].cnt > 0) s.cur[s.keep[i]] = s.nxt[i];
+    for (int i = tid; i < nIni; i += nt)
+        if (s.nxt[i].cnt > 0) { s.cur[s.keep[i]] = s.nxt[i]; if (tables) pc[s.keep[i]] = i; }
     OT_SYNC();
-    ot_for_keys(ks, tid, nt, [&](int j, int k) {
-        const int np = s.keep[ks.get(j, k)];
-        if (s.cur[np].cnt == 1) { s.cur[np].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
-        else ks.set(j, k, (uint16_t)np);
-    });
+    if (!tables)
+        ot_for_keys(ks, tid, nt, [&](int j, int k) {
+            const int np = s.keep[ks.get(j, k)];
+            if (s.cur[np].cnt == 1) { s.cur[np].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
+            else ks.set(j, k, (uint16_t)np);
+        });
     if (tid == 0) s.scal[OT_N] = n0;
     OT_SYNC();
 
     // main loop (:593-738)
     bool finish = false;
+    int sweeps = 0;
     while (!finish) {
         const int prevSize = s.scal[OT_N];
         OT_SYNC();
-        ot_coarse_step(s, ks);
+        if (tables && sweeps == D) { ot_tables_to_keys(s, ks, sweeps, nIni, hX, H, pc); tables = false; }
+        if (tables) {
+            ot_coarse_step<true>(s, ks, sweeps, nIni, pc, pn);
+            int32_t* t = pc; pc = pn; pn = t;
+            OT_STAT(0);
+        } else {
+            ot_coarse_step<false>(s, ks);
+            OT_STAT(1);
+        }
         { OtNode* t = s.cur; s.cur = s.nxt; s.nxt = t; }
+        ++sweeps;
         const int n = s.scal[OT_N], nToExpand = s.scal[OT_NEXP];
         if (n >= N || n == prevSize) finish = true;
         else if (n + nToExpand * 3 > N) {
+            if (tables) { ot_tables_to_keys(s, ks, sweeps, nIni, hX, H, pc); tables = false; }
             while (!finish) {
                 const int prev2 = s.scal[OT_N];
                 OT_SYNC();
@@ -476,6 +613,7 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
             }
         }
     }
+    if (tables) ot_tables_to_keys(s, ks, sweeps, nIni, hX, H, pc);
     OT_SYNC();
     // best key per node (:741-759): largest response, first in input order on ties
     const int n = s.scal[OT_N];

@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 constexpr int kOctThreads = 1024;    // launch bound; the launch uses orbx_extractor::oct_threads
 
 // LDS layout: the node tables of OtShared (capacity NC nodes), then room for KL keys (4 B) and node ids (2 B)
-__device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads)
+__device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads, int TC)
 {
     size_t o = 0;
     s.cur = reinterpret_cast<OtNode*>(mem + o); o += sizeof(OtNode) * NC;
@@ -753,13 +753,23 @@ __device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads
     s.cc2 = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * 2 * NC;
     s.scal = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * 16;
     s.scanTmp = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * (nthreads / 64 + 2);
+    s.tcnt = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * TC;
+    s.tpos = reinterpret_cast<uint16_t*>(mem + o); o += sizeof(uint16_t) * TC;
+    s.tcap = TC;
     return (o + 15) & ~(size_t)15;
 }
-size_t ot_lds_bytes(int NC, int nthreads, int KL)
+size_t ot_lds_bytes(int NC, int nthreads, int KL, int TC)
 {
-    size_t o = sizeof(OtNode) * 2 * NC + sizeof(int32_t) * (4 + 5) * NC + 8 + sizeof(int32_t) * 2 * NC + sizeof(int32_t) * 16 + sizeof(int32_t) * (nthreads / 64 + 2);
+    size_t o = sizeof(OtNode) * 2 * NC + sizeof(int32_t) * (4 + 5) * NC + 8 + sizeof(int32_t) * 2 * NC + sizeof(int32_t) * 16 + sizeof(int32_t) * (nthreads / 64 + 2)
+             + (size_t)TC * 6;
     o = (o + 15) & ~(size_t)15;
     return o + (size_t)KL * 6 + 16;
+}
+// entries of the quadtree's count tables that a level with quota N and nIni roots can put to use (kMaxTableCells at most)
+constexpr int kMaxTableCells = 4096;
+int ot_table_cells(int N, int nIni)
+{
+    return ot_table_size(nIni, ot_table_depth(N, nIni, kMaxTableCells));
 }
 
 // gathers the per-cell candidate slots of a level into the dense key array K (cell-row-major, raster inside a cell: the
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
                                                         const uint16_t* __restrict__ cellcnt, int ncells,
                                                         uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int key_total,
                                                         uint32_t* __restrict__ lvlkp, int kp_total,
-                                                        int32_t* __restrict__ lvlcnt, int nlevels, int NCmax, int KL,
+                                                        int32_t* __restrict__ lvlcnt, int nlevels, int NCmax, int KL, int TC,
                                                         unsigned char* __restrict__ gmem, unsigned long long gstride)
 {
     extern __shared__ __align__(16) unsigned char ot_lds[];
@@ -811,7 +821,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
     // memory instead (KL == 0): the waves of a workgroup share one CU's L1, so barriers order it the same way.  A template
     // parameter rather than a run-time choice, so that the LDS form keeps its DS instructions.
     unsigned char* ot_mem = kTablesInDeviceMemory ? gmem + ((unsigned long long)frame * nlevels + level) * gstride : ot_lds;
-    const size_t keyOff = ot_carve(s, ot_mem, NCmax, kOctThreads);
+    const size_t keyOff = ot_carve(s, ot_mem, NCmax, kOctThreads, TC);
 
     const uint16_t* cnt = cellcnt + (unsigned long long)frame * ncells + L.cell_first;
     const uint32_t* slots = cand + (unsigned long long)frame * cand_total + L.cand_offset;
@@ -846,12 +856,12 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
 __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int nk,
                                                                int W, int H, int nIni, float hX, int N,
                                                                uint32_t* __restrict__ out, int outCap, int32_t* __restrict__ nOut, int NC,
-                                                               int KL, unsigned char* __restrict__ gmem)
+                                                               int KL, int TC, unsigned char* __restrict__ gmem)
 {
     extern __shared__ __align__(16) unsigned char ot_lds[];
     OtShared s;
     unsigned char* ot_mem = gmem ? gmem : ot_lds;
-    const size_t keyOff = ot_carve(s, ot_mem, NC, kOctThreads);
+    const size_t keyOff = ot_carve(s, ot_mem, NC, kOctThreads, TC);
     const uint32_t* K = keys; uint16_t* NO = nodeOf;
     if (nk <= KL) {                     // KL == 0 keeps the keys in device memory
         uint32_t* kl = reinterpret_cast<uint32_t*>(ot_mem + keyOff);
@@ -1548,6 +1558,7 @@ struct orbx_extractor {
     int key_total = 0;
     int max_border_threads = 0;
     int NCmax = 0;
+    int TC = 0;                     // entries of the quadtree's count tables
     int KL = 0;              // keys of one level that fit the quadtree's LDS key arrays
     int oct_threads = 256;
     size_t oct_lds = 0;
@@ -1613,6 +1624,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK(hipGetDevice(&ex->device));
     ex->hlv.resize(geo.nlevels);
     int key_off = 0, ncmax = 0;
+    std::vector<std::pair<int, int> > pending_tc;      // per level: candidates of a busy image (one pixel in 64), count-table cells it would use
     for (int l = 0; l < geo.nlevels; ++l) {
         const LevelGeom& g = geo.lv[l];
         DevLevel d{};
@@ -1632,29 +1644,34 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         ex->max_blur_threads = std::max(ex->max_blur_threads, 4 * g.upr * ((g.h + kBlurRows - 1) / kBlurRows));
         key_off += (g.cand_cap + 3) & ~3;
         ncmax = std::max(ncmax, g.kp_cap);
+        pending_tc.push_back(g.cell_count > 0 ? std::make_pair(g.w * g.h / 64, ot_table_cells(g.quota, g.nIni)) : std::make_pair(0, 0));
         ex->hlv[l] = d;
     }
     ex->key_total = key_off;
     ex->NCmax = std::max(ncmax + 8, 64);
     if (ex->NCmax >= 65535) { set_error("a level's quota of 65527 keypoints or more overflows the quadtree's 16-bit node ids"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
-    // LDS key arrays: as many keys as leave five workgroups resident per CU (160 KB / 5 each); residency matters
-    // more than keeping the largest level's keys out of device memory (measured at 640x480: 3 resident 0.144 ms,
-    // 5 resident 0.110 ms per 256 frames).  Below 512 keys the LDS arrays are not worth having.
-    {
-        const long room = 31L * 1024 - (long)ot_lds_bytes(ex->NCmax, kOctThreads, 0);
-        ex->KL = (int)std::max(0L, room / 6) / 128 * 128;
-        if (ex->KL < 512) ex->KL = 0;
-    }
     // Workgroup size of the quadtree kernel: its key passes scale with the candidates of a level (~1 % of the pixels).
     // Measured per batch: 640x480 256 threads 0.10 ms, 512 +15 %, 1024 2x; 3840x2160 256 threads 2.14 ms, 512 1.19, 1024 0.75.
     {
         const long px = (long)width * height;
         ex->oct_threads = px >= 2000000 ? 1024 : px >= 1000000 ? 512 : 256;
     }
-    ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads, ex->KL);
+    // count tables: room for the levels that a busy image gives enough keys per thread to use them (a level that gets
+    // there against this estimate runs with the room the others left, or walks the keys in every sweep as before)
+    for (const auto& t : pending_tc)
+        if (t.first >= kOtTableMinKeysPerThread * ex->oct_threads) ex->TC = std::max(ex->TC, t.second);
+    // LDS key arrays: as many keys as leave five workgroups resident per CU (160 KB / 5 each); residency matters
+    // more than keeping the largest level's keys out of device memory (measured at 640x480: 3 resident 0.144 ms,
+    // 5 resident 0.110 ms per 256 frames).  Below 512 keys the LDS arrays are not worth having.
+    {
+        const long room = 31L * 1024 - (long)ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC);
+        ex->KL = (int)std::max(0L, room / 6) / 128 * 128;
+        if (ex->KL < 512) ex->KL = 0;
+    }
+    ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads, ex->KL, ex->TC);
     if (ex->oct_lds > 150 * 1024) {          // node tables beyond LDS: per-workgroup slices of device memory, keys there too
         ex->KL = 0;
-        ex->oct_gstride = (ot_lds_bytes(ex->NCmax, kOctThreads, 0) + 255) & ~(size_t)255;
+        ex->oct_gstride = (ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC) + 255) & ~(size_t)255;
         ex->oct_lds = 64;
         HIP_CHECK(hipMalloc(&ex->d_octmem, ex->oct_gstride * geo.nlevels * (size_t)max_batch));
     }
@@ -1805,11 +1822,11 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
         dim3 grid(B, G.nlevels);
         if (ex->d_octmem)
             hipLaunchKernelGGL(k_octree<true>, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, cand, G.cand_total,
-                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL,
+                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL, ex->TC,
                                ex->d_octmem + (size_t)f0 * G.nlevels * ex->oct_gstride, (unsigned long long)ex->oct_gstride);
         else
             hipLaunchKernelGGL(k_octree<false>, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, cand, G.cand_total,
-                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL,
+                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL, ex->TC,
                                (unsigned char*)nullptr, 0ull);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
@@ -2278,20 +2295,21 @@ int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, in
     const int NC = std::max(std::max(N + 3, 4 * nIni) + 9, 64);
     if (NC >= 65535) { set_error("orbx_distribute_octree: N of 65523 or more overflows the 16-bit node ids"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     int KL = key_storage == 0 ? 4096 : 0;
-    size_t lds = ot_lds_bytes(NC, kOctThreads, KL);
+    const int TC = ot_table_cells(N, nIni);
+    size_t lds = ot_lds_bytes(NC, kOctThreads, KL, TC);
     const bool in_device_memory = lds > 150 * 1024;       // node tables beyond LDS
     if (in_device_memory) { KL = 0; lds = 64; }
     int rc = select_device(device);
     if (rc) return rc;
     uint32_t *d_keys = nullptr, *d_out = nullptr; uint16_t* d_no = nullptr; int32_t* d_n = nullptr; unsigned char* d_mem = nullptr;
-    if (in_device_memory) HIP_CHECK(hipMalloc(&d_mem, ot_lds_bytes(NC, kOctThreads, 0)));
+    if (in_device_memory) HIP_CHECK(hipMalloc(&d_mem, ot_lds_bytes(NC, kOctThreads, 0, TC)));
     HIP_CHECK(hipMalloc(&d_keys, sizeof(uint32_t) * std::max(n, 1)));
     HIP_CHECK(hipMalloc(&d_no, sizeof(uint16_t) * std::max(n, 1)));
     HIP_CHECK(hipMalloc(&d_out, sizeof(uint32_t) * NC));
     HIP_CHECK(hipMalloc(&d_n, sizeof(int32_t)));
     if (n) HIP_CHECK(hipMemcpy(d_keys, packed_keys, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree_single), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(256), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL, d_mem);
+    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(256), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL, TC, d_mem);
     HIP_CHECK(hipGetLastError());
     int32_t cnt = 0;
     HIP_CHECK(hipMemcpy(&cnt, d_n, sizeof(int32_t), hipMemcpyDeviceToHost));
