@@ -420,6 +420,9 @@ constexpr int kMaxCellDim = 60;      // cells are at most 59 wide (wCell = ceil(
 constexpr int kSmallCellDim = 38;    // the usual case (wCell 30..38): smaller LDS tiles, more resident wavefronts
 constexpr int kSmallQueue = 480;     // survivor list of a usual cell (a third of its pixels): eight workgroups per CU
 constexpr int kBigQueue = 1024;
+// cells (wavefronts) per workgroup.  One: a workgroup's LDS and wave slots come free when its cell is done, not when the
+// slowest of several cells is (cells differ by the corners they hold); measured 333 -> 321 us per 256 frames against four.
+constexpr int kFastWavesPerBlock = 1;
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
@@ -528,7 +531,7 @@ struct FastCell {
     uint32_t pad;
 };
 
-// One wavefront per cell, four cells per workgroup; no workgroup barrier anywhere.
+// One wavefront per cell, WPB cells per workgroup; no workgroup barrier anywhere.
 //   tile load -> per threshold attempt { pass 1: packed pretest of 256 pixels per round, survivors kept as bits ->
 //   queued -> pass 2: exact score of the queued survivors -> pass 3: strict local maxima among the corners }
 //   -> every maximum finds its own rank in raster order and writes its key.
@@ -537,26 +540,26 @@ struct FastCell {
 // kernel lives on that (its phases wait on LDS and memory round trips): the list is sized for the usual cell, not for
 // the worst one.  A cell with more survivors than the list holds takes the dense path: its rounds are queued and
 // scored one at a time, no corner list is kept, and passes 3 and the emission walk all pixels of the cell instead.
-template <int TS, int TR, int SS, int SR, int MR, int QCAP>
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
+template <int TS, int TR, int SS, int SR, int MR, int QCAP, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= kSmallCellDim + 6 ? 8 : 3, 8))) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
                                                     const FastCell* __restrict__ fcells, int nlist,
                                                     uint32_t* __restrict__ cand, int cand_total,
                                                     uint16_t* __restrict__ cellcnt, int ncells,
                                                     int iniTh, int minTh, int n_frames)
 {
     static_assert(QCAP >= 256 && QCAP % 8 == 0 && (SR * SS) % 16 == 0 && MR <= 64, "list holds at least one round");
-    __shared__ __align__(16) uint8_t s_tile[4][TR * TS];
-    __shared__ __align__(16) uint8_t s_score[4][SR * SS];
-    __shared__ unsigned long long s_mask[4][MR];
-    __shared__ uint16_t s_queue[4][QCAP];
-    __shared__ uint16_t s_base[4][MR];
+    __shared__ __align__(16) uint8_t s_tile[WPB][TR * TS];
+    __shared__ __align__(16) uint8_t s_score[WPB][SR * SS];
+    __shared__ unsigned long long s_mask[WPB][MR];
+    __shared__ uint16_t s_queue[WPB][QCAP];
+    __shared__ uint16_t s_base[WPB][MR];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything derived from it stays scalar
     int frame; uint32_t blk;
-    if (!frame_chunk(blockIdx.x, (nlist + 3) >> 2, n_frames, frame, blk)) return;
-    if ((int)blk * 4 + wave >= nlist) return;
-    const FastCell c = fcells[(int)blk * 4 + wave];
+    if (!frame_chunk(blockIdx.x, (nlist + WPB - 1) / WPB, n_frames, frame, blk)) return;
+    if ((int)blk * WPB + wave >= nlist) return;
+    const FastCell c = fcells[(int)blk * WPB + wave];
     const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + c.src;
     uint8_t* tile = s_tile[wave];
     uint8_t* score = s_score[wave];
@@ -1803,16 +1806,16 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[1], st));
     {
-        // cells up to 38 pixels (the usual 30..38) run with small LDS tiles and five workgroups per CU; the few larger
+        // cells up to 38 pixels (the usual 30..38) run with small LDS tiles (5 KB per cell: 32 wavefronts per CU); the few larger
         // ones (a level whose border-to-border span is just under a multiple of 30) get their own launch
         const int nc = (int)G.cells.size();
         if (ex->n_small)
-            hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 40, kSmallCellDim + 2, 40, kSmallQueue>), dim3(frame_chunk_grid((ex->n_small + 3) / 4, B)),
-                               dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_fast_cells, ex->n_small, cand, G.cand_total, cellcnt, nc,
+            hipLaunchKernelGGL((k_fast_cells<48, kSmallCellDim + 6, 40, kSmallCellDim + 2, 40, kSmallQueue, kFastWavesPerBlock>),
+                               dim3(frame_chunk_grid((ex->n_small + kFastWavesPerBlock - 1) / kFastWavesPerBlock, B)), dim3(64 * kFastWavesPerBlock), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_fast_cells, ex->n_small, cand, G.cand_total, cellcnt, nc,
                                ex->params.ini_th_fast, ex->params.min_th_fast, B);
         if (ex->n_big)
-            hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2, 64, kBigQueue>), dim3(frame_chunk_grid((ex->n_big + 3) / 4, B)),
-                               dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_fast_cells + ex->n_small, ex->n_big, cand, G.cand_total, cellcnt, nc,
+            hipLaunchKernelGGL((k_fast_cells<80, kMaxCellDim + 8, 64, kMaxCellDim + 2, 64, kBigQueue, kFastWavesPerBlock>),
+                               dim3(frame_chunk_grid((ex->n_big + kFastWavesPerBlock - 1) / kFastWavesPerBlock, B)), dim3(64 * kFastWavesPerBlock), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_fast_cells + ex->n_small, ex->n_big, cand, G.cand_total, cellcnt, nc,
                                ex->params.ini_th_fast, ex->params.min_th_fast, B);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
