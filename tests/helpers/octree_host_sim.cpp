@@ -20,12 +20,11 @@ extern "C" int otsim_distribute(const uint32_t* keys, int nk, int minX, int maxX
     std::vector<uint16_t> nodeOf(nk > 0 ? nk : 1);
     const int TC = table_cap < 0 ? ot_table_size(nIni, ot_table_depth(N, nIni, 4096)) : table_cap;
     std::vector<int32_t> tcnt(TC + 1);
-    std::vector<uint16_t> tpos(TC + 1);
+    std::vector<uint16_t> tpos(TC + 1), ent0(NC), ent1(NC), xy(W + H + 1);
     OtShared s{a.data(), b.data(), cc.data(), candPos.data(), pi.data(), cByPi.data(), keep.data(), posToCand.data(), reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(cc2.data()) + 7) & ~(uintptr_t)7), scal.data(), tmp.data(),
-               tcnt.data(), tpos.data(), TC};
+               tcnt.data(), tpos.data(), ent0.data(), ent1.data(), TC, xy.data(), xy.data(), W + H};
     OtMemKeys ks{keys, nodeOf.data(), nk};
-    (void)W;
-    return ot_distribute(s, ks, keys, H, nIni, hX, N, out, cap);
+    return ot_distribute(s, ks, keys, W, H, nIni, hX, N, out, cap);
 }
 
 extern "C" void otsim_sweeps(int* on_tables, int* on_keys, int reset)

@@ -228,8 +228,8 @@ def oracle_level(oracle, img, l):
 
 
 def test_octree_count_tables(vsa, oracle):
-    """Key sets large enough (32 keys per thread and more) for the coarse sweeps to run on the count tables, spread out
-    and clustered (clusters make the sweeps outlast the tables' depth)."""
+    """Large key sets (the split steps run on the count tables), spread out and clustered (clusters make the steps
+    outlast the tables' depth, so that the keys take over half-way)."""
     rng = np.random.default_rng(23)
     for it, (W, H, n, N) in enumerate([(1200, 400, 30000, 300), (1200, 400, 60000, 1500), (608, 448, 20000, 217), (2000, 900, 50000, 4000),
                                        (3808, 2128, 90000, 434), (900, 450, 25000, 40), (1200, 400, 30000, 0)]):

@@ -63,7 +63,8 @@ def test_parallel_formulation_equals_list_version(oracle, vsa):
             t[0] += a.value; t[1] += b.value
         checked += 1
     assert checked > 250
-    # the library's table size covers most of the coarse sweeps; without tables every sweep walks the keys
-    assert sweeps[0][0] == 0 and sweeps[-1][0] > 2 * sweeps[-1][1], sweeps
+    # steps (coarse sweeps and fine steps) run on the tables / walking the keys: the library's table size covers most of
+    # them even for these clustered sets, whose fine steps go far below the tables' depth; without tables all walk the keys
+    assert sweeps[0][0] == 0 and sweeps[-1][0] > sweeps[-1][1], sweeps
     assert sweeps[1][0] > 0 and sweeps[1][1] > 0, sweeps
     print(sweeps)

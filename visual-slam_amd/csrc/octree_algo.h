@@ -19,7 +19,7 @@
 #ifdef ORBX_OCTREE_HOST_SIM
 #include <cmath>
 #define OT_DEV
-// sweeps of the coarse phase by kind (0: on the count tables, 1: walking the keys), for the tests
+// split steps by kind (0: on the count tables, 1: walking the keys), for the tests
 static int ot_sim_sweeps[2];
 #define OT_STAT(i) (++ot_sim_sweeps[i])
 #define OT_HD static inline
@@ -93,8 +93,13 @@ struct OtShared {
     int32_t* scal;         // [16] scalars
     int32_t* scanTmp;      // [NT/64 + 2] block-scan scratch (device)
     int32_t* tcnt;         // [tcap] key counts of the full quadtree's cells down to the table depth (see ot_table_depth)
-    uint16_t* tpos;        // [tcap] list position of the node that stands for a cell when the tables are put to use
+    uint16_t* tpos;        // [tcap] 0xFFFF: the cell's node has been split; else, once the keys are handed over, its list position
+    uint16_t* ent0;        // [NC] table entry of every node of cur / nxt while the steps run on the tables (tcap > 0 only)
+    uint16_t* ent1;        // [NC]
     int tcap;              // capacity of the two tables in entries (0: no tables)
+    uint16_t* xs;          // [xycap] per key column / row: its share of the key's cell index at the tables' depth (see ot_build_axis_tables)
+    uint16_t* ys;
+    int xycap;             // entries of xs and ys together
 };
 enum { OT_N = 0, OT_E = 1, OT_C = 2, OT_RSTAR = 3, OT_NEXP = 4, OT_SEQ = 5, OT_TMP = 6, OT_NSPLIT = 7 };
 
@@ -104,7 +109,7 @@ enum { OT_N = 0, OT_E = 1, OT_C = 2, OT_RSTAR = 3, OT_NEXP = 4, OT_SEQ = 5, OT_T
 // sums give the levels above; the sweeps then work on node records only (their child counts are table look-ups), and one
 // more pass at the end hands every key to its node.  Two passes over the keys instead of two per sweep.
 // Level d (0 = the roots) holds nIni * 4^d cells, cell index = root * 4^d + quadrant path, levels stored back to back.
-constexpr int kOtTableMinKeysPerThread = 32;
+constexpr int kOtTableMinKeysPerThread = 2;
 OT_HD int ot_table_size(int nIni, int d) { long long s = 0, c = nIni; for (int i = 0; i <= d; ++i) { s += c; c *= 4; } return s > 0x7FFFFFFF ? 0x7FFFFFFF : (int)s; }
 OT_HD int ot_table_off(int nIni, int d) { return d <= 0 ? 0 : ot_table_size(nIni, d - 1); }
 // Depth of the tables: the first level with at least N cells (the coarse sweeps stop before the list reaches N nodes, so
@@ -113,7 +118,7 @@ OT_HD int ot_table_depth(int N, int nIni, int tcap)
 {
     int d = 0; long long cells = nIni;
     while (cells < N && d < 7) { cells *= 4; ++d; }
-    while (d > 0 && ot_table_size(nIni, d) > tcap) --d;
+    while (d > 0 && (ot_table_size(nIni, d) > tcap || ((long long)nIni << (2 * d)) > 65536)) --d;   // cell indices are 16-bit
     return d;
 }
 
@@ -184,25 +189,39 @@ static OT_DEV void ot_child_box(const OtNode& p, int q, OtNode& c)
     c.y1 = (int16_t)((q & 2) ? p.y1 : my);
 }
 
-// A key's way down the full quadtree: the box of its cell, refined one level per call exactly as ot_quadrant / ot_child_box do
-struct OtBox { int x0, x1, y0, y1; };
-static OT_DEV void ot_root_box(int r, float hX, int H, OtBox& b)
+static OT_DEV int ot_root_of_x(int x, float hX, int nIni)
 {
-    b.x0 = (int16_t)(int)(hX * (float)r); b.x1 = (int16_t)(int)(hX * (float)(r + 1)); b.y0 = 0; b.y1 = (int16_t)H;
-}
-static OT_DEV int ot_key_root(uint32_t key, float hX, int nIni)
-{
-    const int r = (int)ot_fdiv((float)ot_key_x(key), hX);
+    const int r = (int)ot_fdiv((float)x, hX);
     return r > nIni - 1 ? nIni - 1 : r;
 }
-static OT_DEV int ot_descend(OtBox& b, uint32_t key)
+static OT_DEV int ot_key_root(uint32_t key, float hX, int nIni) { return ot_root_of_x(ot_key_x(key), hX, nIni); }
+
+// The split lines of ot_child_box depend on one axis only: whether a key goes right at depth d follows from its column
+// and the columns of its cell, whether it goes down from its row.  So a key's cell index at depth D (root * 4^D + two bits
+// per level, right + 2 * bottom, first level on top) is xs[column] | ys[row], with xs holding the root and the `right` bits
+// and ys the `bottom` bits, and its cell at depth d < D is that index >> 2 (D - d).  W + H short walks replace one per key.
+static OT_DEV void ot_build_axis_tables(OtShared& s, int W, int H, int nIni, float hX, int D)
 {
-    const int mx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), my = b.y0 + ((b.y1 - b.y0 + 1) >> 1);
-    const int right = ot_key_x(key) >= mx, bottom = ot_key_y(key) >= my;
-    if (right) b.x0 = mx; else b.x1 = mx;
-    if (bottom) b.y0 = my; else b.y1 = my;
-    return right + 2 * bottom;
+    const int tid = OT_TID, nt = OT_NT;
+    for (int i = tid; i < W + H; i += nt) {
+        const bool isx = i < W;
+        const int v = isx ? i : i - W;
+        int lo = 0, hi = (int16_t)H, idx = 0;
+        if (isx) {
+            const int r = ot_root_of_x(v, hX, nIni);
+            lo = (int16_t)(int)(hX * (float)r); hi = (int16_t)(int)(hX * (float)(r + 1));
+            idx = r << (2 * D);
+        }
+        for (int d = 0; d < D; ++d) {
+            const int mid = lo + ((hi - lo + 1) >> 1);
+            const int far = v >= mid;
+            if (far) lo = mid; else hi = mid;
+            idx |= far << (2 * (D - 1 - d) + (isx ? 0 : 1));
+        }
+        (isx ? s.xs : s.ys)[v] = (uint16_t)idx;
+    }
 }
+static OT_DEV int ot_key_cell(const OtShared& s, uint32_t key) { return (int)s.xs[ot_key_x(key)] | (int)s.ys[ot_key_y(key)]; }
 
 // Key storage.  Thread tid owns the keys tid, tid+nt, tid+2nt, ... ("slot" j = key tid + j*nt) for the whole
 // run, and only the owner ever touches a key's node id.  The arrays live in LDS when a level's keys fit
@@ -254,7 +273,7 @@ static OT_DEV void ot_for_keys4(KS& ks, int tid, int nt, L&& look, C&& commit)
 // TABLES: sweep number t of a run on the count tables: pc[p] is the table entry of node p (all nodes with more than one
 // key are depth-t cells), the child counts are look-ups, pn receives the entries of the new list, and no key is touched.
 template <bool TABLES, class KS>
-static OT_DEV void ot_coarse_step(OtShared& s, KS& ks, int t = 0, int nIni = 0, const int32_t* pc = nullptr, int32_t* pn = nullptr)
+static OT_DEV void ot_coarse_step(OtShared& s, KS& ks, int t = 0, int nIni = 0, const uint16_t* pc = nullptr, uint16_t* pn = nullptr)
 {
     const int tid = OT_TID, nt = OT_NT;
     const int n = s.scal[OT_N];
@@ -302,13 +321,14 @@ static OT_DEV void ot_coarse_step(OtShared& s, KS& ks, int t = 0, int nIni = 0, 
                     ch.cnt = cnt;
                     ch.aux = (uint32_t)(seqBase + cex + before);
                     s.nxt[np] = ch;
-                    if (TABLES) pn[np] = offC + 4 * (pc[p] - offT) + q;
+                    if (TABLES) pn[np] = (uint16_t)(offC + 4 * (pc[p] - offT) + q);
                     c[q] = cnt == 1 ? np | kOtSingle : np;   // the key of a one-key child is parked in the child
                     nexp += cnt > 1;
                     ++before;
                 } else c[q] = -1;
             }
             if (nexp) ot_atomic_add(&s.scal[OT_NEXP], nexp);
+            if (TABLES) s.tpos[pc[p]] = 0xFFFF;
         } else {
             s.nxt[C + kex] = s.cur[p];       // nodes with one key keep their relative order at the back
             if (TABLES) pn[C + kex] = pc[p];
@@ -331,30 +351,33 @@ static OT_DEV void ot_coarse_step(OtShared& s, KS& ks, int t = 0, int nIni = 0, 
     OT_SYNC();
 }
 
-// End of a run on the count tables after T sweeps: every key goes to its node.  Walking down from its root a key stops at
-// the first cell that holds it alone (that node keeps the key in its record) or at depth T (the nodes still to be split).
+// A key's node in the current list while the steps run on the count tables: walking down from its root the key stops at
+// the first cell that holds it alone (that node keeps the key in its record: kOtSingle is set) or whose node has not
+// been split (tpos has the list position of every node of the list, and 0xFFFF for the cells whose nodes were split).
+static OT_DEV int ot_walk_to_node(const OtShared& s, uint32_t key, int nIni, int D)
+{
+    const int cell = ot_key_cell(s, key);
+    int off = 0, cells = nIni;
+    for (int d = 0; d <= D; ++d) {
+        const int e = off + (cell >> (2 * (D - d)));
+        const int pos = s.tpos[e];
+        if (s.tcnt[e] == 1) return pos | kOtSingle;
+        if (pos != 0xFFFF) return pos;
+        off += cells; cells *= 4;
+    }
+    return -1;      // not reached: no step on the tables splits a node of depth D
+}
+
+// End of a run on the count tables with steps still to come: every key goes to its node.
 template <class KS>
-static OT_DEV void ot_tables_to_keys(OtShared& s, KS& ks, int T, int nIni, float hX, int H, const int32_t* pc)
+static OT_DEV void ot_tables_to_keys(OtShared& s, KS& ks, int nIni, int D, const uint16_t* pc)
 {
     const int tid = OT_TID, nt = OT_NT;
     const int n = s.scal[OT_N];
     for (int p = tid; p < n; p += nt) s.tpos[pc[p]] = (uint16_t)p;
     OT_SYNC();
     ot_for_keys4(ks, tid, nt,
-        [&](int j, int k) -> int {
-            const uint32_t key = ks.key(j, k);
-            int idx = ot_key_root(key, hX, nIni);
-            OtBox b;
-            ot_root_box(idx, hX, H, b);
-            int off = 0, cells = nIni;
-            for (int d = 0; ; ++d) {
-                const int e = off + idx;
-                if (s.tcnt[e] == 1) return (int)s.tpos[e] | kOtSingle;
-                if (d == T) return (int)s.tpos[e];
-                idx = 4 * idx + ot_descend(b, key);
-                off += cells; cells *= 4;
-            }
-        },
+        [&](int j, int k) -> int { return ot_walk_to_node(s, ks.key(j, k), nIni, D); },
         [&](int j, int k, int np) {
             if (np < 0) return;
             if (np & kOtSingle) { s.cur[np & 0xFFFF].aux = ks.key(j, k); ks.set(j, k, kOtDead); }
@@ -365,11 +388,13 @@ static OT_DEV void ot_tables_to_keys(OtShared& s, KS& ks, int T, int nIni, float
 
 // One split step.  fine == 0: coarse sweep; fine == 1: sorted pass with the cut at N.
 // Updates s.scal[OT_N], OT_NEXP, OT_SEQ; the caller swaps cur/nxt after the call.
-template <class KS>
-static OT_DEV void ot_split_step(OtShared& s, KS& ks, int N, int fine)
+// TABLES: step number t of a run on the count tables (see ot_coarse_step): child counts are look-ups, no key is touched.
+template <bool TABLES, class KS>
+static OT_DEV void ot_split_step(OtShared& s, KS& ks, int N, int fine, int t = 0, int nIni = 0, const uint16_t* pc = nullptr, uint16_t* pn = nullptr)
 {
     const int tid = OT_TID, nt = OT_NT;
     const int n = s.scal[OT_N];
+    const int offT = TABLES ? ot_table_off(nIni, t) : 0, offC = TABLES ? ot_table_off(nIni, t + 1) : 0;
 
     // candidates = nodes with more than one key, in list order
     for (int p = tid; p < n; p += nt) s.keep[p] = s.cur[p].cnt > 1 ? 1 : 0;
@@ -377,18 +402,24 @@ static OT_DEV void ot_split_step(OtShared& s, KS& ks, int N, int fine)
     const int E = ot_block_scan(s.keep, n, s.scanTmp);
     for (int p = tid; p < n; p += nt) {
         const int e = s.keep[p];
-        if (s.cur[p].cnt > 1) { s.candPos[e] = p; s.posToCand[p] = e; s.cc[4 * e] = 0; s.cc[4 * e + 1] = 0; s.cc[4 * e + 2] = 0; s.cc[4 * e + 3] = 0; }
+        if (s.cur[p].cnt > 1) {
+            s.candPos[e] = p; s.posToCand[p] = e;
+            const int32_t* c = TABLES ? &s.tcnt[offC + 4 * (pc[p] - offT)] : nullptr;
+            s.cc[4 * e] = TABLES ? c[0] : 0; s.cc[4 * e + 1] = TABLES ? c[1] : 0; s.cc[4 * e + 2] = TABLES ? c[2] : 0; s.cc[4 * e + 3] = TABLES ? c[3] : 0;
+        }
         else s.posToCand[p] = -1;
     }
     OT_SYNC();
     // child key counts of every candidate
-    ot_for_keys4(ks, tid, nt,
-        [&](int j, int k) -> int {
-            const uint16_t p = ks.get(j, k);
-            return p == kOtDead ? -1 : 4 * s.posToCand[p] + ot_quadrant(s.cur[p], ks.key(j, k));
-        },
-        [&](int, int, int target) { ot_count(s.cc, target); });
-    OT_SYNC();
+    if (!TABLES) {
+        ot_for_keys4(ks, tid, nt,
+            [&](int j, int k) -> int {
+                const uint16_t p = ks.get(j, k);
+                return p == kOtDead ? -1 : 4 * s.posToCand[p] + ot_quadrant(s.cur[p], ks.key(j, k));
+            },
+            [&](int, int, int target) { ot_count(s.cc, target); });
+        OT_SYNC();
+    }
     // processing order
     if (!fine) {
         for (int e = tid; e < E; e += nt) s.pi[e] = e;
@@ -467,20 +498,24 @@ static OT_DEV void ot_split_step(OtShared& s, KS& ks, int N, int fine)
                     ch.cnt = cnt;
                     ch.aux = (uint32_t)(seqBase + cex + before);
                     s.nxt[np] = ch;
+                    if (TABLES) pn[np] = (uint16_t)(offC + 4 * (pc[p] - offT) + q);
                     c[q] = np;
                     nexp += cnt > 1;
                     ++before;
                 } else c[q] = -1;
             }
             if (nexp) ot_atomic_add(&s.scal[OT_NEXP], nexp);
+            if (TABLES) s.tpos[pc[p]] = 0xFFFF;
         } else {
             const int np = C + s.keep[p];
             s.nxt[np] = s.cur[p];
+            if (TABLES) pn[np] = pc[p];
             s.keep[p] = np;
         }
     }
     OT_SYNC();
     // keys follow their nodes
+    if (!TABLES)
     ot_for_keys4(ks, tid, nt,
         [&](int j, int k) -> int {
             const uint16_t p = ks.get(j, k);
@@ -512,15 +547,16 @@ static OT_DEV void ot_split_step(OtShared& s, KS& ks, int N, int fine)
 // number (all threads).
 template <class KS>
 static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
-                                int H, int nIni, float hX, int N, uint32_t* out, int outCap)
+                                int W, int H, int nIni, float hX, int N, uint32_t* out, int outCap)
 {
     const int tid = OT_TID, nt = OT_NT;
-    // the tables pay once a thread has many keys to walk per pass (measured: 88 keys per thread -27 % of the whole
-    // selection, 12 to 20 keys per thread +6 %: zeroing, summing and the deeper walks cost more than the passes saved)
-    const int D = ks.nk >= kOtTableMinKeysPerThread * nt ? ot_table_depth(N, nIni, s.tcap) : 0;
-    int32_t* pc = s.candPos;        // table entries of the nodes of cur / nxt while the sweeps run on the count tables
-    int32_t* pn = s.pi;             // (both arrays are otherwise used by the fine steps only)
+    // the tables pay from two keys per thread on (measured per 256 frames of 640x480 98 -> 95 us, 1241x376 188 -> 154,
+    // per 128 of 1920x1080 431 -> 284, per 64 of 3840x2160 1204 -> 539); below that a key pass is a single round anyway
+    const int D = ks.nk >= kOtTableMinKeysPerThread * nt && W + H <= s.xycap ? ot_table_depth(N, nIni, s.tcap) : 0;
+    uint16_t* pc = s.ent0;          // table entries of the nodes of cur / nxt while the steps run on the count tables
+    uint16_t* pn = s.ent1;
     bool tables = D > 0;
+    if (tables) s.ys = s.xs + W;
     // roots (:551-569)
     for (int i = tid; i < nIni; i += nt) {
         OtNode r;
@@ -535,17 +571,11 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
     if (tables) {
         const int total = ot_table_size(nIni, D);
         for (int i = tid; i < total; i += nt) s.tcnt[i] = 0;
+        ot_build_axis_tables(s, W, H, nIni, hX, D);
         OT_SYNC();
         int32_t* deepest = s.tcnt + ot_table_off(nIni, D);
         ot_for_keys4(ks, tid, nt,
-            [&](int j, int k) -> int {
-                const uint32_t key = ks.key(j, k);
-                int idx = ot_key_root(key, hX, nIni);
-                OtBox b;
-                ot_root_box(idx, hX, H, b);
-                for (int d = 0; d < D; ++d) idx = 4 * idx + ot_descend(b, key);
-                return idx;
-            },
+            [&](int j, int k) -> int { return ot_key_cell(s, ks.key(j, k)); },
             [&](int, int, int idx) { ot_count(deepest, idx); });
         OT_SYNC();
         for (int d = D - 1; d >= 0; --d) {
@@ -571,7 +601,7 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
     OT_SYNC();
     const int n0 = ot_block_scan(s.keep, nIni, s.scanTmp);
     for (int i = tid; i < nIni; i += nt)
-        if (s.nxt[i].cnt > 0) { s.cur[s.keep[i]] = s.nxt[i]; if (tables) pc[s.keep[i]] = i; }
+        if (s.nxt[i].cnt > 0) { s.cur[s.keep[i]] = s.nxt[i]; if (tables) pc[s.keep[i]] = (uint16_t)i; }
     OT_SYNC();
     if (!tables)
         ot_for_keys(ks, tid, nt, [&](int j, int k) {
@@ -588,10 +618,11 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
     while (!finish) {
         const int prevSize = s.scal[OT_N];
         OT_SYNC();
-        if (tables && sweeps == D) { ot_tables_to_keys(s, ks, sweeps, nIni, hX, H, pc); tables = false; }
+        // a step on the tables needs the counts one level below its nodes: past the tables' depth the keys take over
+        if (tables && sweeps == D) { ot_tables_to_keys(s, ks, nIni, D, pc); tables = false; }
         if (tables) {
             ot_coarse_step<true>(s, ks, sweeps, nIni, pc, pn);
-            int32_t* t = pc; pc = pn; pn = t;
+            uint16_t* t = pc; pc = pn; pn = t;
             OT_STAT(0);
         } else {
             ot_coarse_step<false>(s, ks);
@@ -602,32 +633,59 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
         const int n = s.scal[OT_N], nToExpand = s.scal[OT_NEXP];
         if (n >= N || n == prevSize) finish = true;
         else if (n + nToExpand * 3 > N) {
-            if (tables) { ot_tables_to_keys(s, ks, sweeps, nIni, hX, H, pc); tables = false; }
+            // (a fine step that does not reach N splits every node with more than one key, as a coarse sweep does: those
+            // nodes stay the cells of one depth, which is all a step on the tables relies on)
             while (!finish) {
                 const int prev2 = s.scal[OT_N];
                 OT_SYNC();
-                ot_split_step(s, ks, N, 1);
+                if (tables && sweeps == D) { ot_tables_to_keys(s, ks, nIni, D, pc); tables = false; }
+                if (tables) {
+                    ot_split_step<true>(s, ks, N, 1, sweeps, nIni, pc, pn);
+                    uint16_t* t = pc; pc = pn; pn = t;
+                    OT_STAT(0);
+                } else {
+                    ot_split_step<false>(s, ks, N, 1);
+                    OT_STAT(1);
+                }
                 { OtNode* t = s.cur; s.cur = s.nxt; s.nxt = t; }
+                ++sweeps;
                 const int n2 = s.scal[OT_N];
                 if (n2 >= N || n2 == prev2) finish = true;
             }
         }
     }
-    if (tables) ot_tables_to_keys(s, ks, sweeps, nIni, hX, H, pc);
     OT_SYNC();
     // best key per node (:741-759): largest response, first in input order on ties
     const int n = s.scal[OT_N];
     unsigned* best = reinterpret_cast<unsigned*>(s.keep);
-    for (int p = tid; p < n; p += nt) best[p] = 0;
+    for (int p = tid; p < n; p += nt) { best[p] = 0; if (tables) s.tpos[pc[p]] = (uint16_t)p; }
     OT_SYNC();
-    ot_for_keys4(ks, tid, nt,
-        [&](int j, int k) -> int {
-            const uint16_t p = ks.get(j, k);
-            return p == kOtDead ? -1 : (int)(((unsigned)p << 8) | (ks.key(j, k) & 0xFFu));      // node, response
-        },
-        [&](int, int k, int v) {
-            if (v >= 0) ot_atomic_max(&best[v >> 8], ((unsigned)(v & 0xFF) << 24) | (0xFFFFFFu - (unsigned)k));
-        });
+    if (tables)       // the run ended on the tables: the keys find their nodes and compete in the same pass
+        ot_for_keys4(ks, tid, nt,
+            [&](int j, int k) -> int { return ot_walk_to_node(s, ks.key(j, k), nIni, D); },
+            [&](int j, int k, int np) {
+                if (np < 0) return;
+                const uint32_t key = ks.key(j, k);
+                if (np & kOtSingle) s.cur[np & 0xFFFF].aux = key;
+                else {
+                    // (most keys lose against what their node already holds: a plain read spares them the atomic, and
+                    // same-address atomics of one wavefront run one after the other)
+                    const unsigned v = ((key & 0xFFu) << 24) | (0xFFFFFFu - (unsigned)k);
+                    if (v > best[np]) ot_atomic_max(&best[np], v);
+                }
+            });
+    else
+        ot_for_keys4(ks, tid, nt,
+            [&](int j, int k) -> int {
+                const uint16_t p = ks.get(j, k);
+                return p == kOtDead ? -1 : (int)(((unsigned)p << 8) | (ks.key(j, k) & 0xFFu));      // node, response
+            },
+            [&](int, int k, int v) {
+                if (v >= 0) {
+                    const unsigned c = ((unsigned)(v & 0xFF) << 24) | (0xFFFFFFu - (unsigned)k);
+                    if (c > best[v >> 8]) ot_atomic_max(&best[v >> 8], c);
+                }
+            });
     OT_SYNC();
     for (int p = tid; p < n && p < outCap; p += nt) {
         const OtNode& nd = s.cur[p];

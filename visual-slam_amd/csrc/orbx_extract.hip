@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <tuple>
 #include <vector>
 #include <thread>
 #include <string>
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
 constexpr int kOctThreads = 1024;    // launch bound; the launch uses orbx_extractor::oct_threads
 
 // LDS layout: the node tables of OtShared (capacity NC nodes), then room for KL keys (4 B) and node ids (2 B)
-__device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads, int TC)
+__device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads, int TC, int XY)
 {
     size_t o = 0;
     s.cur = reinterpret_cast<OtNode*>(mem + o); o += sizeof(OtNode) * NC;
@@ -758,18 +759,24 @@ __device__ size_t ot_carve(OtShared& s, unsigned char* mem, int NC, int nthreads
     s.scanTmp = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * (nthreads / 64 + 2);
     s.tcnt = reinterpret_cast<int32_t*>(mem + o); o += sizeof(int32_t) * TC;
     s.tpos = reinterpret_cast<uint16_t*>(mem + o); o += sizeof(uint16_t) * TC;
+    s.ent0 = reinterpret_cast<uint16_t*>(mem + o); o += TC ? sizeof(uint16_t) * NC : 0;
+    s.ent1 = reinterpret_cast<uint16_t*>(mem + o); o += TC ? sizeof(uint16_t) * NC : 0;
     s.tcap = TC;
+    s.xs = reinterpret_cast<uint16_t*>(mem + o); o += sizeof(uint16_t) * XY;
+    s.ys = s.xs;                    // set per level: the rows follow the level's columns
+    s.xycap = XY;
     return (o + 15) & ~(size_t)15;
 }
-size_t ot_lds_bytes(int NC, int nthreads, int KL, int TC)
+size_t ot_lds_bytes(int NC, int nthreads, int KL, int TC, int XY)
 {
     size_t o = sizeof(OtNode) * 2 * NC + sizeof(int32_t) * (4 + 5) * NC + 8 + sizeof(int32_t) * 2 * NC + sizeof(int32_t) * 16 + sizeof(int32_t) * (nthreads / 64 + 2)
-             + (size_t)TC * 6;
+             + (size_t)TC * 6 + (TC ? sizeof(uint16_t) * 2 * NC : 0) + sizeof(uint16_t) * XY;
     o = (o + 15) & ~(size_t)15;
     return o + (size_t)KL * 6 + 16;
 }
 // entries of the quadtree's count tables that a level with quota N and nIni roots can put to use (kMaxTableCells at most)
 constexpr int kMaxTableCells = 4096;
+constexpr size_t kOctLdsLimit = 158 * 1024;          // of the 160 KB a workgroup can have
 int ot_table_cells(int N, int nIni)
 {
     return ot_table_size(nIni, ot_table_depth(N, nIni, kMaxTableCells));
@@ -801,7 +808,7 @@ __device__ __attribute__((always_inline)) int octree_level(OtShared& s, uint32_t
     __threadfence_block();
     __syncthreads();
     OtMemKeysT<LOOK> ks{K, NO, nk};
-    return ot_distribute(s, ks, K, L.maxBorderY - kMinBorder, L.nIni, L.hX, L.quota, out, L.kp_cap);
+    return ot_distribute(s, ks, K, L.maxBorderX - kMinBorder, L.maxBorderY - kMinBorder, L.nIni, L.hX, L.quota, out, L.kp_cap);
 }
 
 template <bool kTablesInDeviceMemory>
@@ -810,7 +817,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
                                                         const uint16_t* __restrict__ cellcnt, int ncells,
                                                         uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int key_total,
                                                         uint32_t* __restrict__ lvlkp, int kp_total,
-                                                        int32_t* __restrict__ lvlcnt, int nlevels, int NCmax, int KL, int TC,
+                                                        int32_t* __restrict__ lvlcnt, int nlevels, int NCmax, int KL, int TC, int XY,
                                                         unsigned char* __restrict__ gmem, unsigned long long gstride)
 {
     extern __shared__ __align__(16) unsigned char ot_lds[];
@@ -824,7 +831,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
     // memory instead (KL == 0): the waves of a workgroup share one CU's L1, so barriers order it the same way.  A template
     // parameter rather than a run-time choice, so that the LDS form keeps its DS instructions.
     unsigned char* ot_mem = kTablesInDeviceMemory ? gmem + ((unsigned long long)frame * nlevels + level) * gstride : ot_lds;
-    const size_t keyOff = ot_carve(s, ot_mem, NCmax, kOctThreads, TC);
+    const size_t keyOff = ot_carve(s, ot_mem, NCmax, kOctThreads, TC, XY);
 
     const uint16_t* cnt = cellcnt + (unsigned long long)frame * ncells + L.cell_first;
     const uint32_t* slots = cand + (unsigned long long)frame * cand_total + L.cand_offset;
@@ -859,12 +866,12 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const DevLevel* __restri
 __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* __restrict__ keys, uint16_t* __restrict__ nodeOf, int nk,
                                                                int W, int H, int nIni, float hX, int N,
                                                                uint32_t* __restrict__ out, int outCap, int32_t* __restrict__ nOut, int NC,
-                                                               int KL, int TC, unsigned char* __restrict__ gmem)
+                                                               int KL, int TC, int XY, unsigned char* __restrict__ gmem)
 {
     extern __shared__ __align__(16) unsigned char ot_lds[];
     OtShared s;
     unsigned char* ot_mem = gmem ? gmem : ot_lds;
-    const size_t keyOff = ot_carve(s, ot_mem, NC, kOctThreads, TC);
+    const size_t keyOff = ot_carve(s, ot_mem, NC, kOctThreads, TC, XY);
     const uint32_t* K = keys; uint16_t* NO = nodeOf;
     if (nk <= KL) {                     // KL == 0 keeps the keys in device memory
         uint32_t* kl = reinterpret_cast<uint32_t*>(ot_mem + keyOff);
@@ -874,7 +881,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree_single(const uint32_t* _
         __syncthreads();
     }
     OtMemKeys ks{K, NO, nk};
-    const int n = ot_distribute(s, ks, K, H, nIni, hX, N, out, outCap);
+    const int n = ot_distribute(s, ks, K, W, H, nIni, hX, N, out, outCap);
     if (threadIdx.x == 0) *nOut = n;
 }
 
@@ -1562,6 +1569,7 @@ struct orbx_extractor {
     int max_border_threads = 0;
     int NCmax = 0;
     int TC = 0;                     // entries of the quadtree's count tables
+    int XY = 0;                     // entries of its per-column / per-row cell index tables
     int KL = 0;              // keys of one level that fit the quadtree's LDS key arrays
     int oct_threads = 256;
     size_t oct_lds = 0;
@@ -1627,7 +1635,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK(hipGetDevice(&ex->device));
     ex->hlv.resize(geo.nlevels);
     int key_off = 0, ncmax = 0;
-    std::vector<std::pair<int, int> > pending_tc;      // per level: candidates of a busy image (one pixel in 64), count-table cells it would use
+    std::vector<std::tuple<int, int, int> > pending_tc;      // per level: candidates of a busy image (one pixel in 64), count-table cells it would use
     for (int l = 0; l < geo.nlevels; ++l) {
         const LevelGeom& g = geo.lv[l];
         DevLevel d{};
@@ -1647,7 +1655,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         ex->max_blur_threads = std::max(ex->max_blur_threads, 4 * g.upr * ((g.h + kBlurRows - 1) / kBlurRows));
         key_off += (g.cand_cap + 3) & ~3;
         ncmax = std::max(ncmax, g.kp_cap);
-        pending_tc.push_back(g.cell_count > 0 ? std::make_pair(g.w * g.h / 64, ot_table_cells(g.quota, g.nIni)) : std::make_pair(0, 0));
+        pending_tc.push_back(g.cell_count > 0 ? std::make_tuple(g.w * g.h / 64, ot_table_cells(g.quota, g.nIni), g.maxBorderX - kMinBorder + g.maxBorderY - kMinBorder) : std::make_tuple(0, 0, 0));
         ex->hlv[l] = d;
     }
     ex->key_total = key_off;
@@ -1662,19 +1670,24 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     // count tables: room for the levels that a busy image gives enough keys per thread to use them (a level that gets
     // there against this estimate runs with the room the others left, or walks the keys in every sweep as before)
     for (const auto& t : pending_tc)
-        if (t.first >= kOtTableMinKeysPerThread * ex->oct_threads) ex->TC = std::max(ex->TC, t.second);
+        if (std::get<0>(t) >= kOtTableMinKeysPerThread * ex->oct_threads) {
+            ex->TC = std::max(ex->TC, std::get<1>(t));
+            ex->XY = std::max(ex->XY, (std::get<2>(t) + 7) & ~7);
+        }
+    // ... as long as the node tables stay in LDS with them
+    if (ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC, ex->XY) > kOctLdsLimit) { ex->TC = 0; ex->XY = 0; }
     // LDS key arrays: as many keys as leave five workgroups resident per CU (160 KB / 5 each); residency matters
     // more than keeping the largest level's keys out of device memory (measured at 640x480: 3 resident 0.144 ms,
     // 5 resident 0.110 ms per 256 frames).  Below 512 keys the LDS arrays are not worth having.
     {
-        const long room = 31L * 1024 - (long)ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC);
+        const long room = 31L * 1024 - (long)ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC, ex->XY);
         ex->KL = (int)std::max(0L, room / 6) / 128 * 128;
         if (ex->KL < 512) ex->KL = 0;
     }
-    ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads, ex->KL, ex->TC);
-    if (ex->oct_lds > 150 * 1024) {          // node tables beyond LDS: per-workgroup slices of device memory, keys there too
+    ex->oct_lds = ot_lds_bytes(ex->NCmax, kOctThreads, ex->KL, ex->TC, ex->XY);
+    if (ex->oct_lds > kOctLdsLimit) {        // node tables beyond LDS: per-workgroup slices of device memory, keys there too
         ex->KL = 0;
-        ex->oct_gstride = (ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC) + 255) & ~(size_t)255;
+        ex->oct_gstride = (ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC, ex->XY) + 255) & ~(size_t)255;
         ex->oct_lds = 64;
         HIP_CHECK(hipMalloc(&ex->d_octmem, ex->oct_gstride * geo.nlevels * (size_t)max_batch));
     }
@@ -1825,11 +1838,11 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
         dim3 grid(B, G.nlevels);
         if (ex->d_octmem)
             hipLaunchKernelGGL(k_octree<true>, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, cand, G.cand_total,
-                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL, ex->TC,
+                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL, ex->TC, ex->XY,
                                ex->d_octmem + (size_t)f0 * G.nlevels * ex->oct_gstride, (unsigned long long)ex->oct_gstride);
         else
             hipLaunchKernelGGL(k_octree<false>, grid, dim3(ex->oct_threads), ex->oct_lds, st, ex->d_lv, ex->d_cells, cand, G.cand_total,
-                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL, ex->TC,
+                               cellcnt, (int)G.cells.size(), keys, nodeof, ex->key_total, lvlkp, G.kp_total, lvlcnt, G.nlevels, ex->NCmax, ex->KL, ex->TC, ex->XY,
                                (unsigned char*)nullptr, 0ull);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[3], st));
@@ -2298,21 +2311,23 @@ int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, in
     const int NC = std::max(std::max(N + 3, 4 * nIni) + 9, 64);
     if (NC >= 65535) { set_error("orbx_distribute_octree: N of 65523 or more overflows the 16-bit node ids"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
     int KL = key_storage == 0 ? 4096 : 0;
-    const int TC = ot_table_cells(N, nIni);
-    size_t lds = ot_lds_bytes(NC, kOctThreads, KL, TC);
-    const bool in_device_memory = lds > 150 * 1024;       // node tables beyond LDS
+    int TC = ot_table_cells(N, nIni), XY = (W + H + 7) & ~7;
+    if (ot_lds_bytes(NC, kOctThreads, 0, TC, XY) > kOctLdsLimit) { TC = 0; XY = 0; }
+    size_t lds = ot_lds_bytes(NC, kOctThreads, KL, TC, XY);
+    if (lds > kOctLdsLimit && KL) { KL = 0; lds = ot_lds_bytes(NC, kOctThreads, 0, TC, XY); }
+    const bool in_device_memory = lds > kOctLdsLimit;       // node tables beyond LDS
     if (in_device_memory) { KL = 0; lds = 64; }
     int rc = select_device(device);
     if (rc) return rc;
     uint32_t *d_keys = nullptr, *d_out = nullptr; uint16_t* d_no = nullptr; int32_t* d_n = nullptr; unsigned char* d_mem = nullptr;
-    if (in_device_memory) HIP_CHECK(hipMalloc(&d_mem, ot_lds_bytes(NC, kOctThreads, 0, TC)));
+    if (in_device_memory) HIP_CHECK(hipMalloc(&d_mem, ot_lds_bytes(NC, kOctThreads, 0, TC, XY)));
     HIP_CHECK(hipMalloc(&d_keys, sizeof(uint32_t) * std::max(n, 1)));
     HIP_CHECK(hipMalloc(&d_no, sizeof(uint16_t) * std::max(n, 1)));
     HIP_CHECK(hipMalloc(&d_out, sizeof(uint32_t) * NC));
     HIP_CHECK(hipMalloc(&d_n, sizeof(int32_t)));
     if (n) HIP_CHECK(hipMemcpy(d_keys, packed_keys, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree_single), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(256), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL, TC, d_mem);
+    hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(256), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL, TC, XY, d_mem);
     HIP_CHECK(hipGetLastError());
     int32_t cnt = 0;
     HIP_CHECK(hipMemcpy(&cnt, d_n, sizeof(int32_t), hipMemcpyDeviceToHost));
