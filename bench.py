@@ -466,7 +466,7 @@ def worker(a):
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(stage_bytes[dom] * B), "launch_ms": round(dom_ms, 4),
-                "valu_issue_frac": valu_issue,   # measured share of cycles issuing vector ALU work: what actually bounds this kernel
+                "valu_issue_frac": valu_issue,   # vector instructions x 4 cycles / SIMD cycles: an upper estimate of the issue pipe's load (2 to 4.5 cycles each on this chip)
                 "pipeline_alg_bytes_per_frame": int(a_extract),
                 "pipeline_frac": round(a_extract * (fps / n_gpus) / HBM_PEAK, 4)}
     del frames, kps, desc, counts, job

@@ -29,8 +29,10 @@ for k, d in mean.items():
     rd = 32 * d.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * d.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * d.get("TCC_EA0_RDREQ_128B_sum", 0)
     wr = 32 * d.get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", 0)
     kern[k] = {"read_bytes": int(rd), "write_bytes": int(wr)}
-    # share of the kernel's cycles in which its SIMDs issue vector ALU instructions: a wave64 VALU instruction occupies a
-    # SIMD for 4 cycles, the chip has 1024 SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    # share of the kernel's cycles in which its SIMDs issue vector ALU instructions, pricing every wave64 instruction at
+    # 4 cycles: an upper estimate (measured on this chip, profiles/r02b_valu_rates.md: simple 32-bit instructions issue
+    # every 2 cycles once two waves share a SIMD, the byte / packed / three-operand class every 3.3 to 4.5).  The chip has
+    # 1024 SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs
     if "SQ_INSTS_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
         kern[k]["valu_issue_frac"] = round(d["SQ_INSTS_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 3)
 tot = lambda k, n=1: n * (kern.get(k, {}).get("read_bytes", 0) + kern.get(k, {}).get("write_bytes", 0))
