@@ -147,6 +147,19 @@ def test_batch_matches_single(vsa, oracle):
     ex.close()
 
 
+def test_extractors_of_different_sizes_coexist(vsa):
+    """A large context keeps working after a small one was created (per-kernel limits such as the dynamic LDS size are
+    shared by all contexts of a process: creating the small one must not lower them)."""
+    big = vsa.Extractor(vsa.make_params(8000, 1.2, 12), 3840, 2160, device=0)     # its quadtree wants more LDS than the default limit
+    img = vsa.synth_frame(31, 3840, 2160)
+    kps, desc = big.extract(img)
+    small = vsa.Extractor(vsa.make_params(200, 1.2, 3), 160, 120, device=0)
+    small.extract(vsa.synth_frame(32, 160, 120))
+    kps2, desc2 = big.extract(img)
+    assert len(kps) > 6000 and np.array_equal(kps, kps2) and np.array_equal(desc, desc2)
+    big.close(); small.close()
+
+
 def test_constant_image_gives_no_keypoints(vsa):
     w, h = 320, 240
     ex = vsa.Extractor(vsa.make_params(500, 1.2, 4), w, h, device=0)

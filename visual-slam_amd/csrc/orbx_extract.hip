@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <tuple>
 #include <vector>
 #include <thread>
@@ -31,6 +33,23 @@ using namespace orbx;
             return ORBX_ERR_HIP;                                                                \
         }                                                                                       \
     } while (0)
+
+namespace orbx {
+int raise_dynamic_lds(const void* fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> high;       // (kernel, device) -> limit set so far
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& h = high[std::make_pair(fn, dev)];
+    if (bytes <= h) return (int)hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) h = bytes;
+    return (int)e;
+}
+} // namespace orbx
 
 namespace {
 
@@ -1691,7 +1710,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         ex->oct_lds = 64;
         HIP_CHECK(hipMalloc(&ex->d_octmem, ex->oct_gstride * geo.nlevels * (size_t)max_batch));
     }
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ex->oct_lds));
+    HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<false>), ex->oct_lds));
     HIP_CHECK(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&ex->ev_done, hipEventDisableTiming));
     const size_t B = (size_t)max_batch;
@@ -2326,7 +2345,7 @@ int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, in
     HIP_CHECK(hipMalloc(&d_out, sizeof(uint32_t) * NC));
     HIP_CHECK(hipMalloc(&d_n, sizeof(int32_t)));
     if (n) HIP_CHECK(hipMemcpy(d_keys, packed_keys, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree_single), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_octree_single), lds));
     hipLaunchKernelGGL(k_octree_single, dim3(1), dim3(256), lds, 0, d_keys, d_no, n, W, H, nIni, hX, N, d_out, NC, d_n, NC, KL, TC, XY, d_mem);
     HIP_CHECK(hipGetLastError());
     int32_t cnt = 0;

@@ -19,6 +19,11 @@ constexpr int kFrameFill = 3;    // pixels of the REFLECT_101 frame that later s
 
 void set_error(const std::string& s);
 
+// Raises the dynamic-LDS limit of kernel fn on the current device to at least `bytes` (a hipError_t as int).  The limit
+// belongs to the kernel and the device, not to a launch or a context: it only ever goes up, so that contexts with
+// different needs (a 3840x2160 extractor beside a 640x480 one) do not lower it under each other.  Defined in orbx_extract.hip.
+int raise_dynamic_lds(const void* fn, size_t bytes);
+
 // Constructor tables of ORBextractor (src/ORBextractor.cc:409-469)
 struct ScaleTables {
     int nlevels = 0;

@@ -1069,7 +1069,7 @@ int orbx_search_for_initialization_batch_device(orbx_matcher* m, const orbx_keyp
     const size_t lds = (size_t)cap * kInitLdsPerKeypoint + 16;
     if (lds > 150 * 1024 || cap >= (1 << 16)) { set_error("orbx_search_for_initialization_batch_device: per-frame capacity above 2690 keypoints does not fit the LDS of one CU"); return ORBX_ERR_CAPACITY; }
     HIP_CHECK(hipSetDevice(m->device));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_init_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_init_match), lds));
     const float invW = 64.0f / (maxX - minX), invH = 48.0f / (maxY - minY);      // Frame::mfGridElementWidthInv / HeightInv, src/Frame.cc:101-102
     hipLaunchKernelGGL(k_init_match, dim3(n_pairs), dim3(64), lds, (hipStream_t)stream, d_k1, reinterpret_cast<const uint32_t*>(d_d1), d_n1,
                        d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_n2, cap, minX, minY, invW, invH, d_prev_matched_xy, (float)window, nnratio,
@@ -1101,7 +1101,7 @@ int orbx_search_by_projection_batch_device(orbx_matcher* m, int form,
     HIP_CHECK(hipSetDevice(m->device));
     const float invW = 64.0f / (maxX - minX), invH = 48.0f / (maxY - minY);      // src/Frame.cc:101-102
     const void* fn = form == 0 ? reinterpret_cast<const void*>(k_proj_match<0>) : reinterpret_cast<const void*>(k_proj_match<1>);
-    HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_CHECK((hipError_t)raise_dynamic_lds(fn, lds));
     if (form == 0)
         hipLaunchKernelGGL(k_proj_match<0>, dim3(n_calls), dim3(64), lds, (hipStream_t)stream, d_qu, d_qv, d_qradius, d_qur, d_qlevel, d_qangle,
                            reinterpret_cast<const uint32_t*>(d_qdesc), d_q_transient, d_nq, qcap, d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_uright2,
@@ -1131,7 +1131,7 @@ int orbx_stereo_match_batch_device(orbx_matcher* m, const orbx_keypoint* d_kl, c
     if ((rc = reserve(&m->stage[7], &m->stage_bytes[7], sizeof(uint16_t) * list_stride * (size_t)n_pairs))) return rc;
     const size_t lds = stereo_lds_bytes(n_rows, cap_per_frame);
     if (n_rows < 1 || lds > 150 * 1024) { set_error("image rows / keypoint capacity too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_stereo), lds));
     HIP_CHECK(hipMemcpyAsync(m->stage[6], scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_stereo, dim3(n_pairs), dim3(kStereoThreads), lds, st, d_kl, (const uint32_t*)d_dl, d_nl,
                        d_kr, (const uint32_t*)d_dr, d_nr, cap_per_frame, 0, 0, (const float*)m->stage[6], n_rows, min_d, max_d,
@@ -1169,7 +1169,7 @@ int orbx_stereo_match(orbx_matcher* m, const orbx_keypoint* kl, const uint8_t* d
     if ((rc = reserve(&m->stage[7], &m->stage_bytes[7], sizeof(uint16_t) * list_stride))) return rc;
     const size_t lds = stereo_lds_bytes(n_rows, cap);
     if (n_rows < 1 || lds > 150 * 1024) { set_error("image rows / keypoint count too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_stereo), lds));
     hipLaunchKernelGGL(k_stereo, dim3(1), dim3(kStereoThreads), lds, m->stream, (const orbx_keypoint*)m->stage[0], (const uint32_t*)m->stage[1],
                        (const int32_t*)nullptr, (const orbx_keypoint*)m->stage[2], (const uint32_t*)m->stage[3], (const int32_t*)nullptr, cap, nl, nr,
                        (const float*)m->stage[6], n_rows, min_d, max_d, (uint16_t*)m->stage[7], (unsigned long long)list_stride,
