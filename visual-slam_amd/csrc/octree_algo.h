@@ -11,6 +11,10 @@
 // Keys never move: each key carries the list position of its node, a node with one key keeps that
 // key in its record, and the best key of a larger node is found at the end by an atomic max.
 //
+// Most steps never touch the keys at all: while every node with more than one key is split in every step, the
+// nodes are cells of the full quadtree, whose key counts one counting pass tabulates (see "Count tables" below);
+// the keys are handed to their nodes when the steps are over, or when a step has to go below the tables' depth.
+//
 // The same source builds for the device (one workgroup per (frame, level)) and, with
 // ORBX_OCTREE_HOST_SIM, as a single-thread host simulation used by the CPU unit tests.
 #pragma once
@@ -103,17 +107,20 @@ struct OtShared {
 };
 enum { OT_N = 0, OT_E = 1, OT_C = 2, OT_RSTAR = 3, OT_NEXP = 4, OT_SEQ = 5, OT_TMP = 6, OT_NSPLIT = 7 };
 
-// Count tables.  As long as the coarse sweeps run, every node with more than one key is split in every sweep, so after t
-// sweeps those nodes are exactly the non-empty depth-t cells of the full quadtree under the roots, and a key's cell at any
-// depth follows from its coordinates alone.  One pass over the keys therefore counts the cells of the deepest level D;
-// sums give the levels above; the sweeps then work on node records only (their child counts are table look-ups), and one
-// more pass at the end hands every key to its node.  Two passes over the keys instead of two per sweep.
+// Count tables.  Every coarse sweep, and every fine step that does not reach N, splits every node with more than one key,
+// so after t such steps those nodes are exactly the non-empty depth-t cells of the full quadtree under the roots, and a
+// key's cell at any depth follows from its coordinates alone.  One pass over the keys therefore counts the cells of the
+// deepest level D; sums give the levels above; the steps then work on node records only (their child counts are table
+// look-ups), and one more pass at the end hands every key to its node and ranks it there.  Two passes over the keys
+// instead of two to three per step.  A step that would split nodes of depth D hands the keys over first, and the steps
+// from there on walk them.
 // Level d (0 = the roots) holds nIni * 4^d cells, cell index = root * 4^d + quadrant path, levels stored back to back.
+// Used from kOtTableMinKeysPerThread keys per thread on (below that a pass over the keys is a single round anyway).
 constexpr int kOtTableMinKeysPerThread = 2;
 OT_HD int ot_table_size(int nIni, int d) { long long s = 0, c = nIni; for (int i = 0; i <= d; ++i) { s += c; c *= 4; } return s > 0x7FFFFFFF ? 0x7FFFFFFF : (int)s; }
 OT_HD int ot_table_off(int nIni, int d) { return d <= 0 ? 0 : ot_table_size(nIni, d - 1); }
-// Depth of the tables: the first level with at least N cells (the coarse sweeps stop before the list reaches N nodes, so
-// they rarely go deeper; if they do, the remaining sweeps walk the keys as before), as far as the capacity allows.
+// Depth of the tables: the first level with at least N cells (the steps stop when the list reaches N nodes, so only
+// clustered key sets take them deeper), as far as the capacity allows.
 OT_HD int ot_table_depth(int N, int nIni, int tcap)
 {
     int d = 0; long long cells = nIni;
@@ -226,9 +233,8 @@ static OT_DEV int ot_key_cell(const OtShared& s, uint32_t key) { return (int)s.x
 // Key storage.  Thread tid owns the keys tid, tid+nt, tid+2nt, ... ("slot" j = key tid + j*nt) for the whole
 // run, and only the owner ever touches a key's node id.  The arrays live in LDS when a level's keys fit
 // there and in device memory otherwise.
-// LOOK: how many keys a thread looks up before it commits them (ot_for_keys_pipelined): 4 hides the LDS latency;
-// arrays in device memory want 16 (a round trip there costs about as much as a whole group's arithmetic, and a level
-// of a 3840 x 2160 image gives every thread some ninety keys per pass).
+// LOOK: how many keys a thread looks up before it commits them (ot_for_keys4): 4 hides the LDS latency; 8 or 16 for
+// arrays in device memory gained nothing at 3840 x 2160 (some ninety keys per thread and pass) and cost registers.
 template <int LOOK>
 struct OtMemKeysT {
     static constexpr int kLook = LOOK;

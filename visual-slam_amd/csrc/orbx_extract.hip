@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_borders(uint8_t* __restrict__ pyr, unsi
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxCellDim = 60;      // cells are at most 59 wide (wCell = ceil(width / floor(width/30)))
 constexpr int kSmallCellDim = 38;    // the usual case (wCell 30..38): smaller LDS tiles, more resident wavefronts
-constexpr int kSmallQueue = 480;     // survivor list of a usual cell (a third of its pixels): eight workgroups per CU
+constexpr int kSmallQueue = 480;     // survivor list of a usual cell (a third of its pixels): 5 KB of LDS per cell, 32 cells per CU
 constexpr int kBigQueue = 1024;
 // cells (wavefronts) per workgroup.  One: a workgroup's LDS and wave slots come free when its cell is done, not when the
 // slowest of several cells is (cells differ by the corners they hold); measured 333 -> 321 us per 256 frames against four.
