@@ -54,27 +54,31 @@ def test_cv_round_and_atan2(oracle):
         assert abs((a - np.degrees(np.arctan2(y, x))) % 360) < 0.02 or abs((a - np.degrees(np.arctan2(y, x))) % 360) > 359.98
 
 
-def test_fast_atan2_bitwise_against_numpy_float32(oracle):
-    """cv::fastAtan2 (called at src/ORBextractor.cc:102) restated a second time, in numpy float32 arithmetic (every numpy
-    float32 operation is one IEEE single-precision operation, so no fusing and no wider intermediates): the oracle's C
-    version must agree bit for bit on a million (y, x) pairs, among them integer-valued moments as IC_Angle produces."""
+def numpy_fast_atan2(y, x):
+    """cv::fastAtan2 in numpy float32 arithmetic (every numpy float32 operation is one IEEE single-precision operation, so
+    no fusing and no wider intermediates)."""
     f = np.float32
     rad2deg = f(180.0 / 3.1415926535897932384626433832795)
     p1, p3, p5, p7 = (f(v) * rad2deg for v in (0.9997878412794807, -0.3258083974640975, 0.1555786518463281, -0.04432655554792128))
     eps = f(2.220446049250313e-16)
+    y = np.asarray(y, np.float32); x = np.asarray(x, np.float32)
+    ax, ay = np.abs(x), np.abs(y)
+    swap = ax < ay
+    num = np.where(swap, ax, ay); den = np.where(swap, ay, ax) + eps
+    c = num / den
+    c2 = c * c
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    a = np.where(swap, f(90.0) - a, a)
+    a = np.where(x < 0, f(180.0) - a, a)
+    a = np.where(y < 0, f(360.0) - a, a)
+    return a.astype(np.float32)
 
-    def np_atan2(y, x):
-        ax, ay = np.abs(x), np.abs(y)
-        swap = ax < ay
-        num = np.where(swap, ax, ay); den = np.where(swap, ay, ax) + eps
-        c = num / den
-        c2 = c * c
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
-        a = np.where(swap, f(90.0) - a, a)
-        a = np.where(x < 0, f(180.0) - a, a)
-        a = np.where(y < 0, f(360.0) - a, a)
-        return a.astype(np.float32)
 
+def test_fast_atan2_bitwise_against_numpy_float32(oracle):
+    """cv::fastAtan2 (called at src/ORBextractor.cc:102) restated a second time, in numpy float32 arithmetic: the oracle's C
+    version must agree bit for bit on a million (y, x) pairs, among them integer-valued moments as IC_Angle produces."""
+    f = np.float32
+    np_atan2 = numpy_fast_atan2
     rng = np.random.default_rng(11)
     n = 1_000_000
     y = np.concatenate([rng.integers(-2 ** 23, 2 ** 23, n // 2).astype(np.float32), rng.standard_normal(n // 2).astype(np.float32) * f(1e3)])
@@ -84,6 +88,54 @@ def test_fast_atan2_bitwise_against_numpy_float32(oracle):
     want = np_atan2(y, x)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
     assert got.min() >= 0 and got.max() <= 360
+
+
+def test_orientation_and_descriptor_against_numpy(oracle, vsa):
+    """IC_Angle (src/ORBextractor.cc:76-103) and computeOrbDescriptor (:107-146) restated a second time in numpy, on the
+    oracle's own intermediate images and selected keypoints: the moments as plain sums over the umax disc, the angle
+    through the numpy fastAtan2 above, the 256 tests with float32 products and sums (unfused, as compiled C++ without
+    contraction gives) and round-half-even, bits LSB first.  Angles and descriptors must agree bit for bit with the C
+    oracle's (trig mode 0: cos / sin correctly rounded from double)."""
+    import os, re
+    f = np.float32
+    here = os.path.dirname(os.path.abspath(__file__))
+    txt = open(os.path.join(here, "..", "include", "orbx_pattern.inc")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    pat = np.array([int(v) for v in re.findall(r"-?\d+", txt)], np.int32).reshape(256, 4)
+    assert pat.min() == -13 and pat.max() == 12
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    w, h = 320, 240
+    ex = oracle.Extractor(oracle.make_params(300, 1.2, 4))
+    kps, desc = ex.extract(vsa.synth_frame(77, w, h))
+    assert len(kps) > 200
+    factor = f(3.1415926535897932384626433832795 / 180.0)
+    row = 0
+    for level in range(4):
+        lk = ex.level_keypoints(level)
+        if len(lk) == 0:
+            continue
+        img = ex.level_padded(level).astype(np.int64)[19:-19, 19:-19]
+        blur = ex.level_blurred(level).astype(np.int32)
+        for k in lk:
+            x, y = int(k["x"]), int(k["y"])
+            m10 = m01 = 0
+            for v in range(-15, 16):
+                d = umax[abs(v)]
+                seg = img[y + v, x - d:x + d + 1]
+                m10 += int((seg * np.arange(-d, d + 1)).sum()); m01 += v * int(seg.sum())
+            angle = numpy_fast_atan2(f(m01), f(m10))
+            assert angle.view(np.uint32) == np.float32(k["angle"]).view(np.uint32), (level, x, y)
+            theta = f(angle) * factor
+            a = f(np.cos(np.float64(theta))); b = f(np.sin(np.float64(theta)))
+            px0, py0, px1, py1 = (pat[:, i].astype(np.float32) for i in range(4))
+            r0 = np.rint(px0 * b + py0 * a).astype(np.int32); c0 = np.rint(px0 * a - py0 * b).astype(np.int32)
+            r1 = np.rint(px1 * b + py1 * a).astype(np.int32); c1 = np.rint(px1 * a - py1 * b).astype(np.int32)
+            bits = (blur[y + r0, x + c0] < blur[y + r1, x + c1]).astype(np.uint8)
+            want = np.packbits(bits.reshape(32, 8), axis=1, bitorder="little").ravel()
+            assert np.array_equal(desc[row], want), (level, x, y)
+            row += 1
+    assert row == len(kps)
+    ex.close()
 
 
 RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
