@@ -212,6 +212,59 @@ def test_fast9_against_definition(oracle, vsa):
     assert total > 5000
 
 
+def test_cell_loop_against_numpy(oracle, vsa):
+    """The FAST cell loop of ComputeKeyPointsOctTree (src/ORBextractor.cc:764-828) restated a second time in Python over the
+    numpy FAST above: borders, cell grid (`nCols = width / 30`, `wCell = ceil(width / nCols)`), the clamped 6-pixel overlap,
+    the skipped cells, `FAST(ini)` then `FAST(min)` only for a cell left empty, cell offsets added to the coordinates, cells
+    row by row.  The oracle's candidate list of every level must be the same keys in the same order."""
+    import math
+    rng = np.random.default_rng(8)
+    flat = ((vsa.synth_frame(9, 260, 200).astype(np.int32) - 128) // 6 + 128).astype(np.uint8)      # low contrast: many cells fall back
+    half = vsa.synth_frame(10, 300, 170).copy(); half[:, 150:] = 90                                 # cells with nothing at either threshold
+    cases = [(vsa.synth_frame(8, 320, 240), 500, 4, 20, 7), (flat, 300, 3, 20, 7), (half, 300, 3, 20, 7),
+             (rng.integers(0, 256, (131, 167), dtype=np.uint8), 400, 2, 40, 12)]
+    fallbacks = empties = total = 0
+    for img, nf, nl, ini, mn in cases:
+        ex = oracle.Extractor(oracle.make_params(nf, 1.2, nl, ini, mn))
+        ex.extract(img)
+        for level in range(nl):
+            im = ex.level_padded(level)[19:-19, 19:-19]            # mvImagePyramid[level]
+            rows, cols = im.shape
+            min_b, max_bx, max_by = 16, cols - 16, rows - 16
+            width, height = np.float32(max_bx - min_b), np.float32(max_by - min_b)
+            n_cols, n_rows = int(width / np.float32(30)), int(height / np.float32(30))
+            want = []
+            if n_cols > 0 and n_rows > 0:
+                w_cell, h_cell = math.ceil(width / n_cols), math.ceil(height / n_rows)
+                for i in range(n_rows):
+                    ini_y = min_b + i * h_cell
+                    max_y = ini_y + h_cell + 6
+                    if ini_y >= max_by - 3:
+                        continue
+                    max_y = min(max_y, max_by)
+                    for j in range(n_cols):
+                        ini_x = min_b + j * w_cell
+                        max_x = ini_x + w_cell + 6
+                        if ini_x >= max_bx - 6:
+                            continue
+                        max_x = min(max_x, max_bx)
+                        sub = im[ini_y:max_y, ini_x:max_x]
+                        if sub.shape[0] < 7 or sub.shape[1] < 7:
+                            continue
+                        xs, ys, sc = numpy_fast9(sub, ini)
+                        if len(xs) == 0:
+                            xs, ys, sc = numpy_fast9(sub, mn)
+                            fallbacks += len(xs) > 0
+                            empties += len(xs) == 0
+                        want += [(int(x) + j * w_cell, int(y) + i * h_cell, int(v)) for x, y, v in zip(xs, ys, sc)]
+            cx, cy, cs = ex.level_candidates(level)
+            got = list(zip(cx.tolist(), cy.tolist(), cs.tolist()))
+            assert got == want, (img.shape, level, len(got), len(want))
+            total += len(got)
+        ex.close()
+    assert total > 3000 and fallbacks > 10 and empties > 3, (total, fallbacks, empties)
+
+
 def test_gauss_taps_and_blur(oracle):
     assert oracle.gauss_taps().tolist() == [18, 34, 49, 55, 49, 34, 18]
     const = np.full((20, 24), 77, np.uint8)
@@ -355,6 +408,138 @@ def test_distribute_octree_properties(oracle):
         if len(pts) <= N:
             assert len(sel) == len(pts)          # splitting stopped because every node holds one key
     assert len(oracle.distribute_octree(np.zeros(0, np.int16), np.zeros(0, np.int16), np.zeros(0, np.uint8), 16, 616, 16, 464, 100)) == 0
+
+
+def python_distribute_octree(xs, ys, resp, min_x, max_x, min_y, max_y, N):
+    """DistributeOctTree and DivideNode (src/ORBextractor.cc:480-762) written out a second time, statement by statement,
+    over a Python list used as the std::list (push_front = insert(0)).  Where the reference orders equal-sized nodes by
+    their heap address (:683, which no rerun reproduces) the later-created node counts as the larger, the convention the
+    C oracle documents.  Returns the indices of the kept keypoints in result order."""
+    import math
+    f = np.float32
+
+    class Node:
+        __slots__ = ("ul", "ur", "bl", "br", "keys", "no_more", "seq")
+
+        def __init__(self):
+            self.keys = []; self.no_more = False; self.seq = -1
+
+    counter = [0]
+
+    def divide(nd):
+        half_x = math.ceil(f(nd.ur[0] - nd.ul[0]) / 2)
+        half_y = math.ceil(f(nd.br[1] - nd.ul[1]) / 2)
+        n1, n2, n3, n4 = Node(), Node(), Node(), Node()
+        n1.ul = nd.ul; n1.ur = (nd.ul[0] + half_x, nd.ul[1]); n1.bl = (nd.ul[0], nd.ul[1] + half_y); n1.br = (nd.ul[0] + half_x, nd.ul[1] + half_y)
+        n2.ul = n1.ur; n2.ur = nd.ur; n2.bl = n1.br; n2.br = (nd.ur[0], nd.ul[1] + half_y)
+        n3.ul = n1.bl; n3.ur = n1.br; n3.bl = nd.bl; n3.br = (n1.br[0], nd.bl[1])
+        n4.ul = n3.ur; n4.ur = n2.br; n4.bl = n3.br; n4.br = nd.br
+        for i in nd.keys:
+            if xs[i] < n1.ur[0]:
+                (n1 if ys[i] < n1.br[1] else n3).keys.append(i)
+            elif ys[i] < n1.br[1]:
+                n2.keys.append(i)
+            else:
+                n4.keys.append(i)
+        for c in (n1, n2, n3, n4):
+            if len(c.keys) == 1:
+                c.no_more = True
+        return n1, n2, n3, n4
+
+    n_ini = int(np.round(f(max_x - min_x) / f(max_y - min_y)))        # round(): half away from zero; never a tie for these sizes
+    h_x = f(max_x - min_x) / f(n_ini)
+    nodes = []
+    for i in range(n_ini):
+        ni = Node()
+        ni.ul = (int(h_x * f(i)), 0); ni.ur = (int(h_x * f(i + 1)), 0)
+        ni.bl = (ni.ul[0], max_y - min_y); ni.br = (ni.ur[0], max_y - min_y)
+        nodes.append(ni)
+    ini = list(nodes)
+    for i in range(len(xs)):
+        ini[int(f(xs[i]) / h_x)].keys.append(i)
+    kept = []
+    for nd in nodes:
+        if len(nd.keys) == 1:
+            nd.no_more = True
+        if nd.keys:
+            kept.append(nd)
+    nodes = kept
+    finish = False
+    while not finish:
+        prev_size = len(nodes)
+        to_expand = 0
+        size_and_node = []
+        pos = 0
+        while pos < len(nodes):
+            nd = nodes[pos]
+            if nd.no_more:
+                pos += 1
+                continue
+            for c in divide(nd):
+                if c.keys:
+                    nodes.insert(0, c); pos += 1
+                    if len(c.keys) > 1:
+                        to_expand += 1
+                        c.seq = counter[0]; counter[0] += 1
+                        size_and_node.append((len(c.keys), c))
+            del nodes[pos]
+        if len(nodes) >= N or len(nodes) == prev_size:
+            finish = True
+        elif len(nodes) + to_expand * 3 > N:
+            while not finish:
+                prev_size = len(nodes)
+                prev = sorted(size_and_node, key=lambda t: (t[0], t[1].seq))
+                size_and_node = []
+                for size, nd in reversed(prev):
+                    for c in divide(nd):
+                        if c.keys:
+                            nodes.insert(0, c)
+                            if len(c.keys) > 1:
+                                c.seq = counter[0]; counter[0] += 1
+                                size_and_node.append((len(c.keys), c))
+                    nodes.remove(nd)
+                    if len(nodes) >= N:
+                        break
+                if len(nodes) >= N or len(nodes) == prev_size:
+                    finish = True
+    out = []
+    for nd in nodes:
+        best = nd.keys[0]
+        for k in nd.keys[1:]:
+            if resp[k] > resp[best]:
+                best = k
+        out.append(best)
+    return out
+
+
+def test_distribute_octree_against_python_list_version(oracle):
+    rng = np.random.default_rng(60)
+    checked = 0
+    for it in range(40):
+        W, H = int(rng.integers(90, 700)), int(rng.integers(90, 400))
+        if it % 7 == 0:
+            W, H = 608, 448
+        if round(W / H) < 1:
+            continue
+        n = int(rng.integers(0, 1500 if it % 5 else 60))
+        cx, cy = int(rng.integers(3, W - 3)), int(rng.integers(3, H - 3))
+        pts = set()
+        for _ in range(n):
+            if it % 2 and rng.random() < 0.5:
+                x, y = cx + int(rng.integers(-20, 21)), cy + int(rng.integers(-20, 21))
+            else:
+                x, y = int(rng.integers(3, W - 3)), int(rng.integers(3, H - 3))
+            if 3 <= x <= W - 4 and 3 <= y <= H - 4:
+                pts.add((y // 32, x // 31, y, x))
+        pts = sorted(pts)
+        x = np.array([p[3] for p in pts], np.int16); y = np.array([p[2] for p in pts], np.int16)
+        s = rng.integers(7, 12 if it % 3 == 0 else 250, len(pts)).astype(np.uint8)
+        N = int(rng.integers(1, 260))
+        got = oracle.distribute_octree(x, y, s, 16, 16 + W, 16, 16 + H, N)
+        want = python_distribute_octree(x.tolist(), y.tolist(), s.tolist(), 16, 16 + W, 16, 16 + H, N)
+        assert got.tolist() == want, (it, W, H, len(pts), N)
+        checked += 1
+    assert checked > 30
 
 
 def test_extract_is_deterministic_and_bounded(oracle, vsa):
