@@ -542,6 +542,295 @@ def test_distribute_octree_against_python_list_version(oracle):
     assert checked > 30
 
 
+def c_round(v):
+    """C round(): half away from zero"""
+    import math
+    return int(math.floor(abs(float(v)) + 0.5)) * (1 if v >= 0 else -1)
+
+
+class PythonFrameGrid:
+    """Frame::AssignFeaturesToGrid, PosInGrid and GetFeaturesInArea (src/Frame.cc:230-245, :327-392) written out a second
+    time in Python, float32 where the reference computes in float."""
+
+    def __init__(self, k2, bounds):
+        f = np.float32
+        self.k2 = k2
+        self.min_x, self.max_x, self.min_y, self.max_y = (f(v) for v in bounds)
+        self.inv_w = f(64) / (self.max_x - self.min_x); self.inv_h = f(48) / (self.max_y - self.min_y)      # src/Frame.cc:101-102
+        self.grid = [[[] for _ in range(48)] for _ in range(64)]
+        for i in range(len(k2)):
+            px = c_round((f(k2["x"][i]) - self.min_x) * self.inv_w); py = c_round((f(k2["y"][i]) - self.min_y) * self.inv_h)
+            if 0 <= px < 64 and 0 <= py < 48:
+                self.grid[px][py].append(i)
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        import math
+        f = np.float32
+        k2 = self.k2
+        out = []
+        x, y, r = f(x), f(y), f(r)
+        c0 = max(0, int(math.floor((x - self.min_x - r) * self.inv_w)))
+        if c0 >= 64:
+            return out
+        c1 = min(63, int(math.ceil((x - self.min_x + r) * self.inv_w)))
+        if c1 < 0:
+            return out
+        r0 = max(0, int(math.floor((y - self.min_y - r) * self.inv_h)))
+        if r0 >= 48:
+            return out
+        r1 = min(47, int(math.ceil((y - self.min_y + r) * self.inv_h)))
+        if r1 < 0:
+            return out
+        check = min_level > 0 or max_level >= 0
+        for ix in range(c0, c1 + 1):
+            for iy in range(r0, r1 + 1):
+                for j in self.grid[ix][iy]:
+                    if check:
+                        if k2["octave"][j] < min_level:
+                            continue
+                        if max_level >= 0 and k2["octave"][j] > max_level:
+                            continue
+                    if abs(f(k2["x"][j]) - x) < r and abs(f(k2["y"][j]) - y) < r:
+                        out.append(j)
+        return out
+
+
+def python_hamming(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+def python_three_maxima(sizes):
+    """ComputeThreeMaxima (src/ORBmatcher.cc:1604-1645)"""
+    f = np.float32
+    max1 = max2 = max3 = 0
+    ind1 = ind2 = ind3 = -1
+    for i, sz in enumerate(sizes):
+        if sz > max1:
+            max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i
+        elif sz > max2:
+            max3 = max2; max2 = sz; ind3 = ind2; ind2 = i
+        elif sz > max3:
+            max3 = sz; ind3 = i
+    if f(max2) < f(0.1) * f(max1):
+        ind2 = ind3 = -1
+    elif f(max3) < f(0.1) * f(max1):
+        ind3 = -1
+    return ind1, ind2, ind3
+
+
+def python_rot_bin(angle1, angle2):
+    """src/ORBmatcher.cc:478-483"""
+    f = np.float32
+    rot = f(angle1) - f(angle2)
+    if rot < 0.0:
+        rot = rot + f(360.0)
+    b = c_round(rot * (f(1.0) / f(30)))
+    return 0 if b == 30 else b
+
+
+def python_search_for_initialization(k1, d1, k2, d2, bounds, prev, window, nnratio, check_ori):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:408-523) written out a second time in Python over the grid,
+    distance, histogram and three-maxima restatements above."""
+    f = np.float32
+    features_in_area = PythonFrameGrid(k2, bounds).features_in_area
+    dist_of = python_hamming
+    big = 2 ** 31 - 1
+    nmatches = 0
+    m12 = [-1] * len(k1); m21 = [-1] * len(k2); matched_dist = [big] * len(k2)
+    hist = [[] for _ in range(30)]
+    prev = np.array(prev, np.float32).copy()
+    for i1 in range(len(k1)):
+        if k1["octave"][i1] > 0:
+            continue
+        cand = features_in_area(prev[i1][0], prev[i1][1], window, 0, 0)
+        if not cand:
+            continue
+        best, best2, best_idx = big, big, -1
+        for i2 in cand:
+            d = dist_of(d1[i1], d2[i2])
+            if matched_dist[i2] <= d:
+                continue
+            if d < best:
+                best2 = best; best = d; best_idx = i2
+            elif d < best2:
+                best2 = d
+        if best <= 50 and f(best) < f(best2) * f(nnratio):
+            if m21[best_idx] >= 0:
+                m12[m21[best_idx]] = -1
+                nmatches -= 1
+            m12[i1] = best_idx; m21[best_idx] = i1; matched_dist[best_idx] = best
+            nmatches += 1
+            if check_ori:
+                hist[python_rot_bin(k1["angle"][i1], k2["angle"][best_idx])].append(i1)
+    if check_ori:
+        ind1, ind2, ind3 = python_three_maxima([len(h) for h in hist])
+        for i in range(30):
+            if i in (ind1, ind2, ind3):
+                continue
+            for idx1 in hist[i]:
+                if m12[idx1] >= 0:
+                    m12[idx1] = -1
+                    nmatches -= 1
+    for i1 in range(len(k1)):
+        if m12[i1] >= 0:
+            prev[i1] = (k2["x"][m12[i1]], k2["y"][m12[i1]])
+    return np.array(m12, np.int32), nmatches, prev
+
+
+def test_search_for_initialization_against_python(oracle):
+    from oracle_lib import KEYPOINT_DTYPE
+    rng = np.random.default_rng(77)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    matched_total = 0
+    for it in range(6):
+        n1 = int(rng.integers(150, 500))
+        k1 = np.zeros(n1, KEYPOINT_DTYPE)
+        k1["x"] = rng.uniform(-5, 645, n1).astype(np.float32); k1["y"] = rng.uniform(-5, 485, n1).astype(np.float32)
+        k1["octave"] = rng.integers(0, 3, n1) * (rng.random(n1) < 0.4); k1["angle"] = rng.uniform(0, 360, n1).astype(np.float32)
+        d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+        if it % 2:
+            d1[: n1 // 3] = d1[0]                                    # near-identical descriptors: ties and stolen matches
+        # frame 2: moved and slightly altered copies, one common rotation, plus unrelated features
+        take = rng.permutation(n1)[: int(n1 * 0.8)]
+        extra = int(rng.integers(20, 120))
+        n2 = len(take) + extra
+        k2 = np.zeros(n2, KEYPOINT_DTYPE); d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+        k2["x"][: len(take)] = k1["x"][take] + rng.uniform(-12, 12, len(take)).astype(np.float32)
+        k2["y"][: len(take)] = k1["y"][take] + rng.uniform(-12, 12, len(take)).astype(np.float32)
+        k2["octave"][: len(take)] = k1["octave"][take]
+        rot = np.where(rng.random(len(take)) < 0.8, 40.0, rng.uniform(0, 360, len(take)))
+        k2["angle"][: len(take)] = np.mod(k1["angle"][take] - rot + rng.uniform(-6, 6, len(take)), 360.0).astype(np.float32)
+        flips = rng.random((len(take), 256)) < 0.06
+        d2[: len(take)] = np.bitwise_xor(d1[take], np.packbits(flips, axis=1))
+        k2["x"][len(take):] = rng.uniform(0, 640, extra).astype(np.float32); k2["y"][len(take):] = rng.uniform(0, 480, extra).astype(np.float32)
+        k2["angle"][len(take):] = rng.uniform(0, 360, extra).astype(np.float32)
+        prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+        for window, ratio, check_ori in ((100, 0.9, True), (15, 0.9, True), (30, 0.7, False)):
+            g12, gn, gprev = oracle.search_for_initialization(k1, d1, k2, d2, bounds, prev, window, ratio, check_ori)
+            w12, wn, wprev = python_search_for_initialization(k1, d1, k2, d2, bounds, prev, window, ratio, check_ori)
+            assert gn == wn and np.array_equal(g12, w12), (it, window, ratio, check_ori, gn, wn)
+            assert np.array_equal(gprev.view(np.uint32), wprev.view(np.uint32))
+            matched_total += gn
+    assert matched_total > 500
+
+
+def python_search_by_projection_mappoints(q, k2, d2, uright2, bounds, nnratio, claimed):
+    """Candidate loop and acceptance of SearchByProjection(Frame&, vpMapPoints, th) (src/ORBmatcher.cc:68-125) a second time.
+    q: per projected map point u, v, r (= r * scale[level], :69), ur (mTrackProjXR), level, desc, transient (the point
+    has no observations, so its match does not block later ones: :87-89).  claimed[i] >= 0: feature i holds a map point
+    with observations."""
+    f = np.float32
+    grid = PythonFrameGrid(k2, bounds)
+    claimed = list(claimed)
+    nmatches = 0
+    for i in range(len(q["u"])):
+        lvl = int(q["level"][i])
+        cand = grid.features_in_area(q["u"][i], q["v"][i], q["r"][i], lvl - 1, lvl)
+        if not cand:
+            continue
+        best, best_level, best2, best_level2, best_idx = 256, -1, 256, -1, -1
+        for idx in cand:
+            if claimed[idx] >= 0:
+                continue
+            if uright2 is not None and uright2[idx] > 0:
+                if abs(f(q["ur"][i]) - f(uright2[idx])) > f(q["r"][i]):
+                    continue
+            d = python_hamming(q["desc"][i], d2[idx])
+            if d < best:
+                best2 = best; best = d; best_level2 = best_level; best_level = int(k2["octave"][idx]); best_idx = idx
+            elif d < best2:
+                best_level2 = int(k2["octave"][idx]); best2 = d
+        if best <= 100:
+            if best_level == best_level2 and f(best) > f(nnratio) * f(best2):
+                continue
+            claimed[best_idx] = -2 - i if q["transient"][i] else i
+            nmatches += 1
+    return np.array(claimed, np.int32), nmatches
+
+
+def python_search_by_projection_lastframe(q, k2, d2, uright2, bounds, mode, th_dist, check_ori, claimed):
+    """Candidate loop, acceptance and rotation histogram of SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+    (src/ORBmatcher.cc:1381-1470) a second time; mode 1 = forward (:1389), 2 = backward (:1391), 0 otherwise (:1393)."""
+    f = np.float32
+    grid = PythonFrameGrid(k2, bounds)
+    claimed = list(claimed)
+    nmatches = 0
+    hist = [[] for _ in range(30)]
+    for i in range(len(q["u"])):
+        octv = int(q["level"][i]); radius = q["r"][i]
+        if mode == 1:
+            cand = grid.features_in_area(q["u"][i], q["v"][i], radius, octv)
+        elif mode == 2:
+            cand = grid.features_in_area(q["u"][i], q["v"][i], radius, 0, octv)
+        else:
+            cand = grid.features_in_area(q["u"][i], q["v"][i], radius, octv - 1, octv + 1)
+        if not cand:
+            continue
+        best, best_idx = 256, -1
+        for i2 in cand:
+            if claimed[i2] >= 0:
+                continue
+            if uright2 is not None and uright2[i2] > 0:
+                if abs(f(q["ur"][i]) - f(uright2[i2])) > f(radius):
+                    continue
+            d = python_hamming(q["desc"][i], d2[i2])
+            if d < best:
+                best = d; best_idx = i2
+        if best <= th_dist:
+            claimed[best_idx] = -2 - i if q["transient"][i] else i
+            nmatches += 1
+            if check_ori:
+                hist[python_rot_bin(q["angle"][i], k2["angle"][best_idx])].append(best_idx)
+    if check_ori:
+        ind1, ind2, ind3 = python_three_maxima([len(h) for h in hist])
+        for i in range(30):
+            if i != ind1 and i != ind2 and i != ind3:
+                for idx in hist[i]:
+                    claimed[idx] = -1
+                    nmatches -= 1
+    return np.array(claimed, np.int32), nmatches
+
+
+def test_search_by_projection_against_python(oracle):
+    from oracle_lib import KEYPOINT_DTYPE
+    rng = np.random.default_rng(91)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    scale = 1.2 ** np.arange(8)
+    total = 0
+    for it in range(6):
+        n2 = int(rng.integers(300, 700))
+        k2 = np.zeros(n2, KEYPOINT_DTYPE)
+        k2["x"] = rng.uniform(-4, 756, n2).astype(np.float32); k2["y"] = rng.uniform(-4, 484, n2).astype(np.float32)
+        k2["octave"] = rng.integers(0, 8, n2) * (rng.random(n2) < 0.6); k2["angle"] = rng.uniform(0, 360, n2).astype(np.float32)
+        d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+        uright2 = np.where(rng.random(n2) < 0.5, k2["x"] - rng.uniform(1, 40, n2), -1).astype(np.float32) if it % 2 else None
+        nq = int(rng.integers(200, 500))
+        src = rng.integers(0, n2, nq)                                   # each query comes from a feature of the frame ...
+        src[: nq // 6] = src[0]                                        # ... several from the same one (overwrites, contested features)
+        q = {"u": (k2["x"][src] + rng.uniform(-9, 9, nq)).astype(np.float32), "v": (k2["y"][src] + rng.uniform(-9, 9, nq)).astype(np.float32),
+             "level": np.clip(k2["octave"][src] + rng.integers(-1, 2, nq), 0, 7).astype(np.int32),
+             "angle": np.mod(k2["angle"][src] + np.where(rng.random(nq) < 0.8, 25.0, rng.uniform(0, 360, nq)) + rng.uniform(-5, 5, nq), 360).astype(np.float32),
+             "transient": (rng.random(nq) < 0.3).astype(np.uint8)}
+        q["r"] = (np.where(rng.random(nq) < 0.5, 2.5, 4.0) * rng.choice([1.0, 3.0, 7.0]) * scale[q["level"]]).astype(np.float32)
+        q["ur"] = (q["u"] - rng.uniform(1, 40, nq)).astype(np.float32)
+        flips = rng.random((nq, 256)) < rng.choice([0.05, 0.2])
+        q["desc"] = np.bitwise_xor(d2[src], np.packbits(flips, axis=1))
+        q["u"][:5] = rng.uniform(-300, -100, 5)                         # projections far outside the image
+        claimed0 = np.where(rng.random(n2) < 0.15, 2 ** 31 - 1, -1).astype(np.int32)
+        g, gn = oracle.search_by_projection_mappoints(q["u"], q["v"], q["r"], q["ur"], q["level"], q["desc"], k2, d2, uright2, bounds,
+                                                      0.8, claimed0, transient=q["transient"])
+        w, wn = python_search_by_projection_mappoints(q, k2, d2, uright2, bounds, 0.8, claimed0)
+        assert gn == wn and np.array_equal(g, w), ("map points", it, gn, wn)
+        total += gn
+        for mode, th_dist, check_ori in ((0, 100, True), (1, 100, True), (2, 50, False)):
+            g, gn = oracle.search_by_projection_lastframe(q["u"], q["v"], q["r"], q["ur"], q["level"], q["angle"], q["desc"], k2, d2, uright2,
+                                                          bounds, mode, th_dist, check_ori, claimed0, transient=q["transient"])
+            w, wn = python_search_by_projection_lastframe(q, k2, d2, uright2, bounds, mode, th_dist, check_ori, claimed0)
+            assert gn == wn and np.array_equal(g, w), ("last frame", it, mode, gn, wn)
+            total += gn
+    assert total > 1500
+
+
 def test_extract_is_deterministic_and_bounded(oracle, vsa):
     img = vsa.synth_frame(0, 640, 480)
     ex = oracle.Extractor(oracle.make_params())
