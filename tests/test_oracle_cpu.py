@@ -333,6 +333,29 @@ def test_resize_properties(oracle):
     assert np.array_equal(out, ref)
 
 
+def test_pyramid_chain_against_python(oracle, vsa):
+    """ComputePyramid (src/ORBextractor.cc:1106-1131) a second time in Python over the resize primitive checked above: level
+    sizes from the ORIGINAL size times the float inverse scale, round-half-even (:1111), each level resized from the level
+    before it (:1119), every level inside a 19-pixel BORDER_REFLECT_101 frame taken from the level itself (:1121-1127)."""
+    for w, h, nl, sf in ((320, 240, 5, 1.2), (203, 151, 4, 1.2), (256, 192, 3, 2.0), (300, 220, 4, 1.5)):
+        img = vsa.synth_frame(40 + nl, w, h)
+        ex = oracle.Extractor(oracle.make_params(200, sf, nl))
+        ex.extract(img)
+        inv = [np.float32(1)]
+        scale = [np.float32(1)]
+        for _ in range(1, nl):
+            scale.append(np.float32(np.float64(scale[-1]) * sf))           # mvScaleFactor[i] = mvScaleFactor[i-1] * scaleFactor, the factor a double (:417)
+            inv.append(np.float32(1) / scale[-1])
+        prev = img
+        for level in range(nl):
+            lw, lh = int(np.rint(np.float32(w) * inv[level])), int(np.rint(np.float32(h) * inv[level]))
+            assert ex.level_size(level) == (lw, lh)
+            cur = img if level == 0 else oracle.resize_linear(prev, lw, lh)
+            assert np.array_equal(ex.level_padded(level), np.pad(cur, 19, mode="reflect")), (w, h, level)
+            prev = cur
+        ex.close()
+
+
 def test_fast_hand_cases(oracle):
     # constant image: no corner at any threshold
     assert len(oracle.fast9(np.full((40, 40), 90, np.uint8), 7)[0]) == 0
@@ -829,6 +852,58 @@ def test_search_by_projection_against_python(oracle):
             assert gn == wn and np.array_equal(g, w), ("last frame", it, mode, gn, wn)
             total += gn
     assert total > 1500
+
+
+def test_stereo_row_search_against_python(oracle):
+    """The Hamming part of Frame::ComputeStereoMatches (src/Frame.cc:476-549) a second time in Python: the row table of the
+    right keypoints (every row within 2 * scale of the keypoint), per left keypoint the candidates of its row
+    (`vRowIndices[vL]`, the float index truncated), the octave band, the disparity range, best distance below TH_HIGH."""
+    import math
+    from oracle_lib import KEYPOINT_DTYPE
+    f = np.float32
+    rng = np.random.default_rng(13)
+    scale = (1.2 ** np.arange(8)).astype(np.float32)
+    n_rows = 480
+    found = 0
+    for it in range(4):
+        nr = int(rng.integers(300, 700)); nl = int(rng.integers(300, 700))
+        kr = np.zeros(nr, KEYPOINT_DTYPE)
+        kr["x"] = rng.uniform(19, 733, nr).astype(np.float32); kr["y"] = rng.uniform(19, 461, nr).astype(np.float32)
+        kr["octave"] = rng.integers(0, 8, nr)
+        dr = rng.integers(0, 256, (nr, 32), dtype=np.uint8)
+        src = rng.integers(0, nr, nl)
+        kl = np.zeros(nl, KEYPOINT_DTYPE)
+        kl["x"] = (kr["x"][src] + rng.uniform(-5, 70, nl)).astype(np.float32)
+        kl["y"] = (kr["y"][src] + rng.uniform(-3, 3, nl)).astype(np.float32)
+        kl["octave"] = np.clip(kr["octave"][src] + rng.integers(-2, 3, nl), 0, 7)
+        dl = np.bitwise_xor(dr[src], np.packbits(rng.random((nl, 256)) < 0.1, axis=1))
+        min_d, max_d = f(0), f(47.906 / 0.11)                                          # :496-498 with EuRoC's bf and b
+        rows = [[] for _ in range(n_rows)]
+        for i_r in range(nr):
+            r = f(2.0) * scale[kr["octave"][i_r]]
+            for yi in range(int(math.floor(f(kr["y"][i_r]) - r)), int(math.ceil(f(kr["y"][i_r]) + r)) + 1):
+                rows[yi].append(i_r)
+        want_d = np.full(nl, -1, np.int32); want_i = np.full(nl, -1, np.int32)
+        for i_l in range(nl):
+            cand = rows[int(kl["y"][i_l])]
+            if not cand:
+                continue
+            min_u, max_u = f(kl["x"][i_l]) - max_d, f(kl["x"][i_l]) - min_d
+            if max_u < 0:
+                continue
+            best, best_r = 100, 0
+            for i_r in cand:
+                if kr["octave"][i_r] < kl["octave"][i_l] - 1 or kr["octave"][i_r] > kl["octave"][i_l] + 1:
+                    continue
+                if min_u <= f(kr["x"][i_r]) <= max_u:
+                    d = python_hamming(dl[i_l], dr[i_r])
+                    if d < best:
+                        best, best_r = d, i_r
+            want_d[i_l], want_i[i_l] = best, best_r
+        got_d, got_i = oracle.stereo_match(kl, dl, kr, dr, scale, n_rows, float(min_d), float(max_d))
+        assert np.array_equal(got_d, want_d) and np.array_equal(got_i, want_i), it
+        found += int(np.count_nonzero((got_d >= 0) & (got_d < 75)))
+    assert found > 400
 
 
 def test_extract_is_deterministic_and_bounded(oracle, vsa):
