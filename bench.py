@@ -273,38 +273,58 @@ def leg_stereo(cx, vsa, np, steps, warmup, B=128, nfeatures=1200):
     torch = cx.torch
     W, H = 752, 480
     p = vsa.make_params(nfeatures=nfeatures, nlevels=8)
-    left = ExtractJob(cx, vsa, np, p, W, H, B, 1, B, seed0=cx.rank * 100000 + 30, stereo_right=False, n_unique=16)
-    right = ExtractJob(cx, vsa, np, p, W, H, B, 1, B, seed0=cx.rank * 100000 + 30, stereo_right=True, n_unique=16)
-    m = vsa.Matcher(device=cx.local)
-    cap = left.cap
-    bd = torch.zeros((B, cap), dtype=torch.int32, device=cx.dev)
-    bi, sad = torch.zeros_like(bd), torch.zeros_like(bd)
-    ur = torch.zeros((B, cap), dtype=torch.float32, device=cx.dev)
-    dp = torch.zeros_like(ur)
+    # two independent halves of the batch, each with its own left and right extractor context, matcher context and pair
+    # of streams: four streams in all (the process has four hardware queues), so one half's row search and refinement
+    # run beside the other half's extraction
+    G = 2 if B >= 2 else 1
     scale = vsa.scale_tables(p)["scale"]
     bf, fx = 47.90639384423901, 435.2046959714599
-    s0, s1 = left.streams[0], right.streams[0]
+
+    class Half:
+        def __init__(self, g, n):
+            seed = cx.rank * 100000 + 30 + 1000 * g
+            self.n = n
+            self.left = ExtractJob(cx, vsa, np, p, W, H, n, 1, n, seed0=seed, stereo_right=False, n_unique=16)
+            self.right = ExtractJob(cx, vsa, np, p, W, H, n, 1, n, seed0=seed, stereo_right=True, n_unique=16)
+            self.m = vsa.Matcher(device=cx.local)
+            self.cap = self.left.cap
+            self.bd = torch.zeros((n, self.cap), dtype=torch.int32, device=cx.dev)
+            self.bi, self.sad = torch.zeros_like(self.bd), torch.zeros_like(self.bd)
+            self.ur = torch.zeros((n, self.cap), dtype=torch.float32, device=cx.dev)
+            self.dp = torch.zeros_like(self.ur)
+
+        def step(self):
+            left, right, cap, n = self.left, self.right, self.cap, self.n
+            s0, s1 = left.streams[0], right.streams[0]
+            left.step()
+            right.step()
+            s0.wait_stream(s1)
+            self.m.stereo_match_batch_device(left.kps.data_ptr(), left.desc.data_ptr(), left.counts.data_ptr(), right.kps.data_ptr(),
+                                             right.desc.data_ptr(), right.counts.data_ptr(), cap, n, scale, H, 0.0, fx,
+                                             self.bd.data_ptr(), self.bi.data_ptr(), s0.cuda_stream)
+            left.exs[0].stereo_refine_batch_device(right.exs[0], left.kps.data_ptr(), left.counts.data_ptr(), right.kps.data_ptr(), cap, n,
+                                                   self.bd.data_ptr(), self.bi.data_ptr(), bf, 0.0, fx, self.ur.data_ptr(), self.dp.data_ptr(),
+                                                   self.sad.data_ptr(), s0.cuda_stream)
+            s1.wait_stream(s0)
+
+        def close(self):
+            self.left.close(); self.right.close(); self.m.close()
+
+    halves = [Half(g, B // G + (1 if g < B % G else 0)) for g in range(G)]
 
     def step():
-        left.step()
-        right.step()
-        s0.wait_stream(s1)
-        m.stereo_match_batch_device(left.kps.data_ptr(), left.desc.data_ptr(), left.counts.data_ptr(), right.kps.data_ptr(),
-                                    right.desc.data_ptr(), right.counts.data_ptr(), cap, B, scale, H, 0.0, fx,
-                                    bd.data_ptr(), bi.data_ptr(), s0.cuda_stream)
-        left.exs[0].stereo_refine_batch_device(right.exs[0], left.kps.data_ptr(), left.counts.data_ptr(), right.kps.data_ptr(), cap, B,
-                                               bd.data_ptr(), bi.data_ptr(), bf, 0.0, fx, ur.data_ptr(), dp.data_ptr(), sad.data_ptr(),
-                                               s0.cuda_stream)
-        s1.wait_stream(s0)
+        for h in halves:
+            h.step()
 
     t = cx.timed(step, steps, warmup)
-    mean_kp = 0.5 * (left.mean_kp() + right.mean_kp())
-    matched = float((ur >= 0).sum().item()) / B
-    left.close(); right.close(); m.close()
+    mean_kp = sum(0.5 * (h.left.mean_kp() + h.right.mean_kp()) * h.n for h in halves) / B
+    matched = sum(float((h.ur >= 0).sum().item()) for h in halves) / B
+    for h in halves:
+        h.close()
     _, a_img = alg_bytes_per_image(vsa, p, W, H, mean_kp)
     pps = cx.world * B * steps / t
     return {"name": "stereo_752x480", "workload": f"{B} HBM-resident 752x480 pairs per GPU per step, nFeatures={nfeatures} (EuRoC.yaml), left + right "
-                                                  "ORBextractor on two contexts, stereo row-band Hamming search + SAD refinement",
+                                                  "ORBextractor contexts for each half of the batch (four streams), stereo row-band Hamming search + SAD refinement",
             "value": pps, "unit": "pairs/s", "ms_per_step": 1e3 * t / steps, "steps": steps, "scaling": "weak",
             "mean_keypoints_per_image": round(mean_kp, 1), "mean_stereo_matches_per_pair": round(matched, 1),
             "alg_bytes_per_pair": int(2 * a_img), "achieved_GBps_per_gpu": round(2 * a_img * pps / cx.world / 1e9, 1),
@@ -482,10 +502,10 @@ def worker(a):
                                           f"one batch of {a.kitti_frames} HBM-resident 1241x376 frames, nFeatures=2000, split over the ranks "
                                           "(BASELINE configs[2]; one step = the whole batch)"))
         torch.cuda.empty_cache()
-        configs.append(leg_config_extract(cx, vsa, np, "uhd_3840x2160", 3840, 2160, 8000, 12, 128, False, 2, 64, max(2, min(a.steps, 6)), 1,
-                                          "128 HBM-resident 3840x2160 frames per GPU per step (two contexts of 64: a level's quadtree is "
-                                          "one workgroup, so a 16-frame batch leaves most CUs idle during that stage), nFeatures=8000, "
-                                          "12 levels (BASELINE configs[3])"))
+        configs.append(leg_config_extract(cx, vsa, np, "uhd_3840x2160", 3840, 2160, 8000, 12, 128, False, 4, 32, max(2, min(a.steps, 6)), 1,
+                                          "128 HBM-resident 3840x2160 frames per GPU per step (four contexts of 32: a level's quadtree is "
+                                          "one workgroup, so small batches leave most CUs idle during that stage unless other contexts "
+                                          "fill them), nFeatures=8000, 12 levels (BASELINE configs[3])"))
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ Hamming workload
