@@ -814,6 +814,30 @@ def python_search_by_projection_lastframe(q, k2, d2, uright2, bounds, mode, th_d
     return np.array(claimed, np.int32), nmatches
 
 
+def python_search_by_projection_keyframe(q, k2, d2, bounds, claimed):
+    """Candidate loop and acceptance of SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:362-401)
+    a second time: KeyFrame::GetFeaturesInArea without levels (src/KeyFrame.cc:1311-1350), features that are matched
+    already skipped, level band predicted-1 .. predicted, best distance within TH_LOW."""
+    grid = PythonFrameGrid(k2, bounds)
+    claimed = list(claimed)
+    nmatches = 0
+    for i in range(len(q["u"])):
+        lvl = int(q["level"][i])
+        best, best_idx = 256, -1
+        for idx in grid.features_in_area(q["u"][i], q["v"][i], q["r"][i]):
+            if claimed[idx] >= 0:
+                continue
+            if k2["octave"][idx] < lvl - 1 or k2["octave"][idx] > lvl:
+                continue
+            d = python_hamming(q["desc"][i], d2[idx])
+            if d < best:
+                best, best_idx = d, idx
+        if best <= 50:
+            claimed[best_idx] = i
+            nmatches += 1
+    return np.array(claimed, np.int32), nmatches
+
+
 def test_search_by_projection_against_python(oracle):
     from oracle_lib import KEYPOINT_DTYPE
     rng = np.random.default_rng(91)
@@ -851,6 +875,10 @@ def test_search_by_projection_against_python(oracle):
             w, wn = python_search_by_projection_lastframe(q, k2, d2, uright2, bounds, mode, th_dist, check_ori, claimed0)
             assert gn == wn and np.array_equal(g, w), ("last frame", it, mode, gn, wn)
             total += gn
+        g, gn = oracle.search_by_projection_keyframe(q["u"], q["v"], q["r"], q["level"], q["desc"], k2, d2, bounds, claimed0)
+        w, wn = python_search_by_projection_keyframe(q, k2, d2, bounds, claimed0)
+        assert gn == wn and np.array_equal(g, w), ("key frame", it, gn, wn)
+        total += gn
     assert total > 1500
 
 
