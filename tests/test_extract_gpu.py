@@ -160,6 +160,28 @@ def test_extractors_of_different_sizes_coexist(vsa):
     big.close(); small.close()
 
 
+def test_noise_images(vsa, oracle):
+    """Images unlike the benchmark's: white noise and a noisy scene, where a tenth of the pixels are corners (tens of
+    thousands of candidates in a 640x480 level: dense FAST cells, long quadtree key lists, every node split many times)."""
+    rng = np.random.default_rng(5)
+    for w, h, nf, nl, ini, mn, kind in [(640, 480, 1000, 8, 7, 3, "noise"), (640, 480, 3000, 8, 20, 7, "noise"),
+                                        (1241, 376, 2000, 8, 12, 5, "scene"), (800, 600, 5000, 6, 5, 2, "noise")]:
+        if kind == "noise":
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        else:
+            img = (vsa.synth_frame(3, w, h).astype(np.int32) + rng.integers(-25, 26, (h, w))).clip(0, 255).astype(np.uint8)
+        ex = vsa.Extractor(vsa.make_params(nf, 1.2, nl, ini, mn), w, h, max_batch=1, device=0)
+        oex = oracle.Extractor(oracle.make_params(nf, 1.2, nl, ini, mn))
+        kps, desc = ex.extract(img)
+        okps, odesc = oex.extract(img, cap=nf + 64 * nl)
+        assert len(oex.level_candidates(0)[0]) > 20000
+        assert len(kps) == len(okps) >= nf, (w, h, kind)
+        for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+            assert np.array_equal(kps[f], okps[f]), (w, h, kind, f)
+        assert np.array_equal(desc, odesc), (w, h, kind)
+        ex.close(); oex.close()
+
+
 def test_constant_image_gives_no_keypoints(vsa):
     w, h = 320, 240
     ex = vsa.Extractor(vsa.make_params(500, 1.2, 4), w, h, device=0)
