@@ -52,6 +52,31 @@ __global__ void NAME(unsigned* out, long long* cyc, unsigned a, unsigned b) { \
 #define I_MOV(r)   asm volatile("v_mov_b32 %0, %1" : "+v"(r) : "v"(va));
 #define I_DOT4(r)  asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(r) : "v"(va), "v"(vb));
 
+#define I_LSHL(r)  asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(r));
+#define I_LSHR(r)  asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(r));
+#define I_ASHR(r)  asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(r));
+#define I_SUB(r)   asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r) : "v"(va));
+#define I_OR(r)    asm volatile("v_or_b32 %0, %0, %1" : "+v"(r) : "v"(va));
+#define I_XOR(r)   asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r) : "v"(va));
+#define I_MAXU(r)  asm volatile("v_max_u32 %0, %0, %1" : "+v"(r) : "v"(va));
+#define I_MINI(r)  asm volatile("v_min_i32 %0, %0, %1" : "+v"(r) : "v"(va));
+#define I_ADD3(r)  asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r) : "v"(va), "v"(vb));
+#define I_LSHLADD(r) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(r) : "v"(va));
+#define I_ALIGNB(r) asm volatile("v_alignbyte_b32 %0, %0, %1, 1" : "+v"(r) : "v"(va));
+#define I_DOT2(r)  asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(r) : "v"(va), "v"(vb));
+#define I_MED3(r)  asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(r) : "v"(va), "v"(vb));
+#define I_BITOP3(r) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x40" : "+v"(r) : "v"(va), "v"(vb));
+#define I_CNDMASK(r) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r) : "v"(va) : "vcc");
+#define I_MUL24(r) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(r) : "v"(va));
+#define I_PKMULF(r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r) : "v"(va));
+#define I_ADDF(r)  asm volatile("v_add_f32 %0, %0, %1" : "+v"(r) : "v"(va));
+#define I_MIN3(r)  asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(r) : "v"(va), "v"(vb));
+#define I_CVTI(r)  asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(r));
+
+KERNEL(k_lshl, I_LSHL) KERNEL(k_lshr, I_LSHR) KERNEL(k_ashr, I_ASHR) KERNEL(k_sub, I_SUB) KERNEL(k_or, I_OR) KERNEL(k_xor, I_XOR)
+KERNEL(k_maxu, I_MAXU) KERNEL(k_mini, I_MINI) KERNEL(k_add3, I_ADD3) KERNEL(k_lshladd, I_LSHLADD) KERNEL(k_alignb, I_ALIGNB) KERNEL(k_dot2, I_DOT2)
+KERNEL(k_med3, I_MED3) KERNEL(k_bitop3, I_BITOP3) KERNEL(k_cndmask, I_CNDMASK) KERNEL(k_mul24, I_MUL24) KERNEL(k_mulf, I_PKMULF) KERNEL(k_addf, I_ADDF)
+KERNEL(k_min3, I_MIN3) KERNEL(k_cvti, I_CVTI)
 KERNEL(k_add, I_ADD) KERNEL(k_and, I_AND) KERNEL(k_andor, I_ANDOR) KERNEL(k_perm, I_PERM) KERNEL(k_pkmax, I_PKMAX) KERNEL(k_pkadd, I_PKADD)
 KERNEL(k_pksubs, I_PKSUBS) KERNEL(k_max3, I_MAX3) KERNEL(k_min16, I_MIN16) KERNEL(k_sad, I_SAD) KERNEL(k_mad24, I_MAD24) KERNEL(k_mulhi24, I_MULHI24)
 KERNEL(k_mullo, I_MULLO) KERNEL(k_fma, I_FMA) KERNEL(k_lshlor, I_LSHLOR) KERNEL(k_cmpsel, I_CMPSEL) KERNEL(k_bfe, I_BFE) KERNEL(k_sdwa, I_SDWA)
@@ -66,7 +91,12 @@ int main()
                     {"v_mad_u32_u24", k_mad24, 1}, {"v_mul_hi_u32_u24", k_mulhi24, 1}, {"v_mul_lo_u32", k_mullo, 1}, {"v_fma_f32", k_fma, 1},
                     {"v_lshl_or_b32", k_lshlor, 1}, {"v_cmp+v_cndmask", k_cmpsel, 2}, {"v_bfe_u32", k_bfe, 1}, {"v_add_u32_sdwa", k_sdwa, 1},
                     {"v_add_u32_dpp", k_dpp, 1}, {"v_bcnt_u32_b32", k_bcnt, 1}, {"v_cvt_f32_ubyte0", k_cvt, 1}, {"v_xad_u32", k_xad, 1}, {"v_mov_b32", k_mov, 1},
-                    {"v_dot4_u32_u8", k_dot4, 1} };
+                    {"v_dot4_u32_u8", k_dot4, 1},
+                    {"v_lshlrev_b32", k_lshl, 1}, {"v_lshrrev_b32", k_lshr, 1}, {"v_ashrrev_i32", k_ashr, 1}, {"v_sub_u32", k_sub, 1}, {"v_or_b32", k_or, 1},
+                    {"v_xor_b32", k_xor, 1}, {"v_max_u32", k_maxu, 1}, {"v_min_i32", k_mini, 1}, {"v_add3_u32", k_add3, 1}, {"v_lshl_add_u32", k_lshladd, 1},
+                    {"v_alignbyte_b32", k_alignb, 1}, {"v_dot2_u32_u16", k_dot2, 1}, {"v_med3_u32", k_med3, 1}, {"v_bitop3_b32", k_bitop3, 1},
+                    {"v_cndmask_b32", k_cndmask, 1}, {"v_mul_u32_u24", k_mul24, 1}, {"v_mul_f32", k_mulf, 1}, {"v_add_f32", k_addf, 1},
+                    {"v_min3_i32", k_min3, 1}, {"v_cvt_f32_i32", k_cvti, 1} };
     unsigned* d_out; long long* d_cyc;
     const int blocks = 256;
     CHECK(hipMalloc(&d_out, 4096 * 4));

@@ -447,41 +447,50 @@ constexpr int kFastWavesPerBlock = 1;
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-// exact score of the pixel at tile address t (ring offsets in tile coordinates, row stride TS)
+// smallest / largest of sixteen values with three-input instructions (a two-input minimum of 32-bit values issues no
+// faster than a three-input one on this chip)
+// (written as instructions: left to itself the compiler shares two-input minima between neighbouring triples, which
+// needs fewer operations but more issue time here)
+__device__ __forceinline__ int min3_op(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int max3_op(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int min16i(const int (&m)[16])
+{
+    // three partial chains, so that consecutive instructions do not wait for each other
+    const int a = min3_op(min3_op(m[0], m[1], m[2]), m[3], m[4]);
+    const int b = min3_op(min3_op(m[5], m[6], m[7]), m[8], m[9]);
+    const int c = min3_op(min3_op(m[10], m[11], m[12]), m[13], m[14]);
+    return min3_op(min3_op(a, b, c), m[15], m[15]);
+}
+__device__ __forceinline__ int max16i(const int (&m)[16])
+{
+    const int a = max3_op(max3_op(m[0], m[1], m[2]), m[3], m[4]);
+    const int b = max3_op(max3_op(m[5], m[6], m[7]), m[8], m[9]);
+    const int c = max3_op(max3_op(m[10], m[11], m[12]), m[13], m[14]);
+    return max3_op(max3_op(a, b, c), m[15], m[15]);
+}
+
+// exact score of the pixel at tile address t (ring offsets in tile coordinates, row stride TS).  With ring pixels p and
+// centre v: max over the arcs of min over an arc of (v - p) is v - A, A the smallest arc maximum of p; the bright side
+// likewise is B - v, B the largest arc minimum -- so the ring is reduced as it is read, without the sixteen differences.
 template <int TS>
 __device__ __forceinline__ int fast_score(const uint8_t* t)
 {
     const int v = t[0];
-    int d[16];
-    d[0] = v - t[3 * TS];
-    d[1] = v - t[3 * TS + 1];
-    d[2] = v - t[2 * TS + 2];
-    d[3] = v - t[TS + 3];
-    d[4] = v - t[3];
-    d[5] = v - t[-TS + 3];
-    d[6] = v - t[-2 * TS + 2];
-    d[7] = v - t[-3 * TS + 1];
-    d[8] = v - t[-3 * TS];
-    d[9] = v - t[-3 * TS - 1];
-    d[10] = v - t[-2 * TS - 2];
-    d[11] = v - t[-TS - 3];
-    d[12] = v - t[-3];
-    d[13] = v - t[TS - 3];
-    d[14] = v - t[2 * TS - 2];
-    d[15] = v - t[3 * TS - 1];
+    const int p[16] = {t[3 * TS], t[3 * TS + 1], t[2 * TS + 2], t[TS + 3], t[3], t[-TS + 3], t[-2 * TS + 2], t[-3 * TS + 1],
+                       t[-3 * TS], t[-3 * TS - 1], t[-2 * TS - 2], t[-TS - 3], t[-3], t[TS - 3], t[2 * TS - 2], t[3 * TS - 1]};
     int lo3[16], hi3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        lo3[k] = min3_op(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+        hi3[k] = max3_op(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
     }
-    int dark = -256, bright = 256;
+    int arcmax[16], arcmin[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        dark = max(dark, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));     // min over ring k..k+8
-        bright = min(bright, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15])); // max over ring k..k+8
+        arcmax[k] = max3_op(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);     // ring k..k+8
+        arcmin[k] = min3_op(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
     }
-    return max(dark, -bright) - 1;
+    return max(v - min16i(arcmax), max16i(arcmin) - v) - 1;
 }
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
