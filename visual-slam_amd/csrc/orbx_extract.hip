@@ -560,7 +560,9 @@ struct FastCell {
     uint32_t pad;
 };
 
-// One wavefront per cell, WPB cells per workgroup; no workgroup barrier anywhere.
+// One wavefront per cell, WPB cells per workgroup; no workgroup barrier anywhere.  Seven wavefronts per SIMD are asked
+// for, not eight: at 64 registers the score pass spills (the spill traffic cost the pipeline 2 %), and between five and
+// eight wavefronts per SIMD the kernel's time does not change -- it is bound by vector issue.
 //   tile load -> per threshold attempt { pass 1: packed pretest of 256 pixels per round, survivors kept as bits ->
 //   queued -> pass 2: exact score of the queued survivors -> pass 3: strict local maxima among the corners }
 //   -> every maximum finds its own rank in raster order and writes its key.
@@ -570,7 +572,7 @@ struct FastCell {
 // the worst one.  A cell with more survivors than the list holds takes the dense path: its rounds are queued and
 // scored one at a time, no corner list is kept, and passes 3 and the emission walk all pixels of the cell instead.
 template <int TS, int TR, int SS, int SR, int MR, int QCAP, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= kSmallCellDim + 6 ? 8 : 3, 8))) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= kSmallCellDim + 6 ? 7 : 3, 8))) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
                                                     const FastCell* __restrict__ fcells, int nlist,
                                                     uint32_t* __restrict__ cand, int cand_total,
                                                     uint16_t* __restrict__ cellcnt, int ncells,
