@@ -40,7 +40,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step (spread over the contexts: 256 per launch by default)")
     ap.add_argument("--contexts", type=int, default=4,
                     help="extractor contexts per GPU, each on its own HIP stream with batch/contexts frames "
                          "(the reference runs two extractors concurrently for stereo, src/Frame.cc:78-81); a process has "
@@ -267,7 +267,7 @@ def leg_config_extract(cx, vsa, np, name, W, H, nfeatures, nlevels, frames_total
             "achieved_GBps_per_gpu": round(a_img * fps / cx.world / 1e9, 1), "frac_hbm": round(a_img * fps / cx.world / HBM_PEAK, 4)}
 
 
-def leg_stereo(cx, vsa, np, steps, warmup, B=128, nfeatures=1200):
+def leg_stereo(cx, vsa, np, steps, warmup, B=512, nfeatures=1200):
     """BASELINE configs[1]: 752x480 pairs, left and right extraction on two contexts / streams, then the row-band Hamming
     search (src/Frame.cc:466-549) and the sub-pixel refinement (:551-639); camera constants of Examples/Stereo/EuRoC.yaml."""
     torch = cx.torch
@@ -440,13 +440,14 @@ def worker(a):
     frames, kps, desc, counts, cap, uniq = job.frames, job.kps, job.desc, job.counts, job.cap, job.uniq
     job.close()
 
-    # per-stage device time: HIP events recorded by the library on the launch stream around each stage, whole batch
-    # in one context on one stream (separate steps, same workload)
-    ex = vsa.Extractor(p, W, H, max_batch=B, device=cx.local)
+    # per-stage device time: HIP events recorded by the library on the launch stream around each stage, one launch of
+    # the size the timed region used (a context's share of the batch) alone on one stream (separate steps, same frames)
+    PB = job.chunk
+    ex = vsa.Extractor(p, W, H, max_batch=PB, device=cx.local)
     stream = torch.cuda.current_stream().cuda_stream
 
     def profiled_step():
-        ex.extract_batch_device(frames.data_ptr(), W, W * H, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+        ex.extract_batch_device(frames.data_ptr(), W, W * H, PB, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
 
     profiled_step()
     torch.cuda.synchronize()
@@ -465,16 +466,16 @@ def worker(a):
     stages = {}
     for i, name in enumerate(vsa.STAGES):
         ms = float(stage_ms[i])
-        gbps = stage_bytes[name] * B / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        gbps = stage_bytes[name] * PB / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         stages[name] = {"ms": round(ms, 4), "alg_GBps": round(gbps, 1), "frac_hbm": round(gbps * 1e9 / HBM_PEAK, 4)}
     dom = max((n for n in vsa.STAGES if stage_bytes[n] > 0), key=lambda n: stage_ms[vsa.STAGES.index(n)])
     dom_ms = float(stage_ms[vsa.STAGES.index(dom)])
-    achieved = stage_bytes[dom] * B / (dom_ms * 1e-3) / 1e9
+    achieved = stage_bytes[dom] * PB / (dom_ms * 1e-3) / 1e9
     # HBM bytes per launch of that stage's kernels from the stored rocprofv3 --pmc passes (tools/pmc_traffic.py): only
     # valid for the kernels they were taken on, so the file's build stamp must equal the loaded library's
     traffic, traffic_src, valu_issue = None, None, None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile) and (W, H, B, a.nfeatures, a.nlevels) == (640, 480, 256, 1000, 8):
+    if os.path.exists(tfile) and (W, H, PB, a.nfeatures, a.nlevels) == (640, 480, 256, 1000, 8):
         with open(tfile) as f:
             tj = json.load(f)
         if tj.get("build_stamp") != vsa.build_stamp():
@@ -485,7 +486,7 @@ def worker(a):
             valu_issue = tj.get("kernels_mean_per_launch", {}).get(dom_kernel, {}).get("valu_issue_frac") if dom_kernel else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "alg_bytes_per_launch": int(stage_bytes[dom] * B), "launch_ms": round(dom_ms, 4),
+                "alg_bytes_per_launch": int(stage_bytes[dom] * PB), "launch_ms": round(dom_ms, 4),
                 "valu_issue_frac": valu_issue,   # vector instructions x 4 cycles / SIMD cycles: an upper estimate of the issue pipe's load (2 to 4.5 cycles each on this chip)
                 "pipeline_alg_bytes_per_frame": int(a_extract),
                 "pipeline_frac": round(a_extract * (fps / n_gpus) / HBM_PEAK, 4)}
@@ -497,7 +498,7 @@ def worker(a):
         ksteps = max(2, min(a.steps, 20))
         configs.append(leg_stereo(cx, vsa, np, ksteps, 2))
         torch.cuda.empty_cache()
-        configs.append(leg_config_extract(cx, vsa, np, "kitti_1241x376", 1241, 376, 2000, 8, a.kitti_frames, True, 4, 128,
+        configs.append(leg_config_extract(cx, vsa, np, "kitti_1241x376", 1241, 376, 2000, 8, a.kitti_frames, True, 4, 256,
                                           max(2, min(a.steps, 5)), 1,
                                           f"one batch of {a.kitti_frames} HBM-resident 1241x376 frames, nFeatures=2000, split over the ranks "
                                           "(BASELINE configs[2]; one step = the whole batch)"))
@@ -526,7 +527,7 @@ def worker(a):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"ORBextractor {W}x{H} nFeatures={a.nfeatures} nLevels={a.nlevels} scale=1.2 ini=20 min=7, "
                                    f"{B} HBM-resident frames per GPU per step (BASELINE configs[0] shape, batched)",
-                       "frames_per_gpu_per_step": B, "contexts_per_gpu": C, "mean_keypoints_per_frame": round(mean_kp, 1),
+                       "frames_per_gpu_per_step": B, "contexts_per_gpu": C, "frames_per_launch": PB, "mean_keypoints_per_frame": round(mean_kp, 1),
                        "parallelism": f"frames sharded over {n_gpus} GPU(s), no collective"},
             "ranks_seen": seen, "build_stamp": vsa.build_stamp(),
             "roofline": roofline, "stages": stages, "configs": configs, "hamming": hamming, "cpu_baseline": cpu,
