@@ -1706,11 +1706,12 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         }
     // ... as long as the node tables stay in LDS with them
     if (ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC, ex->XY) > kOctLdsLimit) { ex->TC = 0; ex->XY = 0; }
-    // LDS key arrays: as many keys as leave five workgroups resident per CU (160 KB / 5 each); residency matters
-    // more than keeping the largest level's keys out of device memory (measured at 640x480: 3 resident 0.144 ms,
-    // 5 resident 0.110 ms per 256 frames).  Below 512 keys the LDS arrays are not worth having.
+    // LDS key arrays: as many keys as leave four workgroups resident per CU (160 KB / 4 each).  Measured per 256 frames
+    // with the count tables in place, budgets of 23 / 26 / 31 / 40 / 52 KB: 640x480 98 / 97 / 95 / 87 / 115 us (at 40 KB
+    // the largest level's keys just fit), 480x640 92 -> 86, 752x480 101 -> 103, 1241x376 and 1920x1080 unchanged (their
+    // node tables leave no room for keys either way).  Below 512 keys the LDS arrays are not worth having.
     {
-        const long room = 31L * 1024 - (long)ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC, ex->XY);
+        const long room = 40L * 1024 - (long)ot_lds_bytes(ex->NCmax, kOctThreads, 0, ex->TC, ex->XY);
         ex->KL = (int)std::max(0L, room / 6) / 128 * 128;
         if (ex->KL < 512) ex->KL = 0;
     }
