@@ -104,18 +104,18 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Frame-major work split for one-dimensional grids of 8 * ceil(B/8) * chunks workgroups.  Workgroups are dealt
-// round-robin over the 8 XCDs (observed behaviour, relied on for locality only), so workgroups whose index is
-// congruent mod 8 share an L2: all chunks of frame f go to indices congruent to f mod 8, one frame after the
-// other, and the lines of a frame that several chunks touch are fetched from memory once.
-__device__ __forceinline__ bool frame_chunk(uint32_t id, uint32_t chunks, int n_frames, int& frame, uint32_t& chunk)
+// Frame-major work split over grids of 8 x chunks x ceil(B/8) workgroups.  Workgroups are dealt round-robin over the
+// 8 XCDs in linear order, x fastest (observed behaviour, relied on for locality only), so workgroups with the same
+// blockIdx.x share an L2: all chunks of frame f go to x = f mod 8, one frame after the other, and the lines of a frame
+// that several chunks touch are fetched from memory once.  (Three grid dimensions instead of one spare every wavefront
+// a division by the chunk count.)
+__device__ __forceinline__ bool frame_chunk(int n_frames, int& frame, uint32_t& chunk)
 {
-    const uint32_t j = id >> 3, fh = j / chunks;
-    chunk = j - fh * chunks;
-    frame = (int)(fh * 8u + (id & 7u));
+    chunk = blockIdx.y;
+    frame = (int)(blockIdx.z * 8u + blockIdx.x);
     return frame < n_frames;
 }
-__host__ inline unsigned frame_chunk_grid(unsigned chunks, int n_frames) { return 8u * (unsigned)((n_frames + 7) / 8) * chunks; }
+__host__ inline dim3 frame_chunk_grid(unsigned chunks, int n_frames) { return dim3(8u, chunks, (unsigned)((n_frames + 7) / 8)); }
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_level0_colour(const uint8_t* __restrict
                                                        int c0, int c1, int c2)
 {
     int frame; uint32_t blk;
-    if (!frame_chunk(blockIdx.x, (L.cpr * L.h + 255) >> 8, n_frames, frame, blk)) return;
+    if (!frame_chunk(n_frames, frame, blk)) return;
     const uint32_t i = blk * 256 + threadIdx.x;
     if (i >= (uint32_t)(L.cpr * L.h)) return;
     uint32_t y, ch;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img,
                                                 uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L, int n_frames)
 {
     int frame; uint32_t blk;
-    if (!frame_chunk(blockIdx.x, (L.cpr * L.h + 255) >> 8, n_frames, frame, blk)) return;
+    if (!frame_chunk(n_frames, frame, blk)) return;
     const uint32_t i = blk * 256 + threadIdx.x;
     if (i >= (uint32_t)(L.cpr * L.h)) return;
     uint32_t y, ch;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
 {
     const uint32_t nthreads = (uint32_t)(D.gpr * ((D.h + kResizeRows - 1) / kResizeRows));
     int frame; uint32_t blk;
-    if (!frame_chunk(blockIdx.x, (nthreads + 255) >> 8, n_frames, frame, blk)) return;
+    if (!frame_chunk(n_frames, frame, blk)) return;
     const uint32_t i = blk * 256 + threadIdx.x;
     if (i >= nthreads) return;
     uint32_t rb, gx;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything derived from it stays scalar
     int frame; uint32_t blk;
-    if (!frame_chunk(blockIdx.x, (nlist + WPB - 1) / WPB, n_frames, frame, blk)) return;
+    if (!frame_chunk(n_frames, frame, blk)) return;
     if ((int)blk * WPB + wave >= nlist) return;
     const FastCell c = fcells[(int)blk * WPB + wave];
     const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + c.src;
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 {
     __shared__ __align__(16) uint8_t s_stage[4][16 * kBlurUnitBytes];
     int frame; uint32_t chunk;
-    if (!frame_chunk(blockIdx.x, (uint32_t)(nlevels * blocks_per_level), n_frames, frame, chunk)) return;
+    if (!frame_chunk(n_frames, frame, chunk)) return;
     const uint32_t level = chunk / (uint32_t)blocks_per_level, blk = chunk - level * (uint32_t)blocks_per_level;
     const DevLevel& L = lv[level];
     const uint32_t upr = (uint32_t)L.upr;                              // units (4 threads, 16 pixels) per strip row
@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // slot arithmetic stays scalar
     int frame; uint32_t chunk;
-    if (!frame_chunk(blockIdx.x, (kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), n_frames, frame, chunk)) return;
+    if (!frame_chunk(n_frames, frame, chunk)) return;
     const int slot0 = ((int)chunk * 4 + wave) * kKpPerWave;
     if (slot0 >= kp_total) return;
     uint4* win = s_win[wave];
