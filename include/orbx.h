@@ -110,6 +110,15 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
                               ptrdiff_t frame_stride, int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc,
                               int32_t* d_counts, int cap_per_frame, void* stream);
 
+/* Zero-copy input (no counterpart in the reference, whose ComputePyramid copies the image into its padded level 0,
+ * src/ORBextractor.cc:1124-1128): where level 0 of the context's pyramid lives.  A producer that can write its
+ * grey frames there -- frame f, row y, column x at d_images[f * frame_stride + y * row_stride + x], f < max_batch --
+ * (orbx_remap_batch_device, a colour conversion, an upload) and then passes exactly this pointer and these strides to
+ * orbx_extract_batch_device spares the batch its copy of the input: only the REFLECT_101 frame around the frames is
+ * written.  The bytes between the rows belong to the pyramid's frame and may be overwritten by either side.  Grey
+ * input only; any other pointer or stride is copied as before. */
+int orbx_extractor_input_view(orbx_extractor* ex, uint8_t** d_images, ptrdiff_t* row_stride, ptrdiff_t* frame_stride);
+
 /* Pinhole camera with the radial-tangential model of the reference's settings files (Camera.fx .. Camera.k3,
  * src/Tracking.cc:56-80): K = [fx 0 cx; 0 fy cy; 0 0 1] and dist = k1, k2, p1, p2, k3 as mK / mDistCoef hold them (floats). */
 typedef struct orbx_camera { float fx, fy, cx, cy; float k1, k2, p1, p2, k3; } orbx_camera;

@@ -506,3 +506,50 @@ def test_host_batch_pipeline(vsa, oracle):
     k2, d2, c2 = ex.extract_batch(np.ascontiguousarray(padded[3:6, :, :w]))
     assert np.array_equal(c2, counts[3:6]) and np.array_equal(d2[1, :c2[1]], want[4][1])
     ex.close()
+
+
+def test_input_view_skips_the_copy_and_changes_nothing(vsa, oracle):
+    """Frames written straight into the context's input view (level 0 of the pyramid) give the same keypoints,
+    descriptors and padded levels as the same frames passed in a plain buffer, and both equal the oracle."""
+    import torch
+    w, h, B = 640, 480, 3
+    p = vsa.make_params(1000, 1.2, 8, 20, 7)
+    imgs = np.stack([vsa.synth_frame(40 + i, w, h) for i in range(B)])
+    ex = vsa.Extractor(p, w, h, max_batch=B, device=0)
+    cap = ex.cap
+    d = torch.from_numpy(imgs).cuda()
+    outs = []
+    for use_view in (False, True):
+        kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        counts = torch.zeros(B, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        if use_view:
+            ptr, rs, fs = ex.input_view()
+            assert rs >= w and fs >= rs * h
+            # a producer on the device: strided copy of the frames into the view (rows rs apart, frames fs apart)
+            torch.as_tensor(ex.input_view_array(B), device="cuda").copy_(d)
+            torch.cuda.synchronize()
+            ex.extract_batch_device(ptr, rs, fs, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+        else:
+            ex.extract_batch_device(d.data_ptr(), w, w * h, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+        torch.cuda.synchronize()
+        levels = [[ex.pyramid_level(f, l) for l in range(8)] for f in range(B)]
+        outs.append((kps.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy(), levels))
+        # spoil level 0 between the two runs so that the second cannot pass on what the first left there
+        if not use_view:
+            ex.extract_batch_device(torch.zeros_like(d).data_ptr(), w, w * h, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+            torch.cuda.synchronize()
+    (k0, d0, c0, l0), (k1, d1, c1, l1) = outs
+    assert np.array_equal(c0, c1) and c0.min() > 500
+    assert np.array_equal(k0.view(np.uint32), k1.view(np.uint32)) and np.array_equal(d0, d1)
+    for f in range(B):
+        for l in range(8):
+            assert np.array_equal(l0[f][l], l1[f][l]), (f, l)
+    oex = oracle.Extractor(oracle.make_params(1000, 1.2, 8, 20, 7))
+    for f in range(B):
+        okps, odesc = oex.extract(imgs[f], cap=cap)
+        assert c1[f] == len(okps)
+        assert np.array_equal(d1[f, :c1[f]], odesc)
+        assert np.array_equal(l1[f][0], oex.level_padded(0))
+    ex.close()

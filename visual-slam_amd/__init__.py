@@ -70,6 +70,7 @@ _SIGS = {
     "orbx_extract": (_i, [_vp, _vp, _pd, _vp, _vp, _i, C.POINTER(_i)]),
     "orbx_extract_batch": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i, _vp]),
+    "orbx_extractor_input_view": (_i, [_vp, C.POINTER(_vp), C.POINTER(_pd), C.POINTER(_pd)]),
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _pd]),
     "orbx_pyramid_levels": (_i, [_vp, _i, _vp, _vp]),
     "orbx_pyramid_level_device": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd)]),
@@ -300,6 +301,24 @@ class Extractor:
 
     def extract_batch_device(self, d_images, row_stride, frame_stride, n_frames, d_kps, d_desc, d_counts, cap, stream=None):
         _check(lib.orbx_extract_batch_device(self.h, d_images, row_stride, frame_stride, n_frames, d_kps, d_desc, d_counts, cap, stream))
+
+    def input_view(self):
+        """(device pointer, row stride, frame stride) of the place where frames can be written to skip the input copy."""
+        ptr, rs, fs = _vp(), _pd(), _pd()
+        _check(lib.orbx_extractor_input_view(self.h, C.byref(ptr), C.byref(rs), C.byref(fs)))
+        return ptr.value, rs.value, fs.value
+
+    def input_view_array(self, n_frames=None):
+        """The input view as an object with __cuda_array_interface__ (n_frames x height x width bytes, strided), e.g. for
+        torch.as_tensor(ex.input_view_array(), device="cuda")."""
+        ptr, rs, fs = self.input_view()
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (int(n_frames or self.max_batch), self.height, self.width), "strides": (fs, rs, 1),
+                                      "typestr": "|u1", "data": (ptr, False), "version": 2}
+        return v
 
     def undistort_points(self, cam, xy):
         xy = np.ascontiguousarray(xy, np.float32)

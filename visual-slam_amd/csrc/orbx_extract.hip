@@ -493,6 +493,26 @@ __device__ __forceinline__ int fast_score(const uint8_t* t)
     return max(v - min16i(arcmax), max16i(arcmin) - v) - 1;
 }
 
+// One side of the exact score: DARK gives v - A (A the smallest arc maximum), otherwise B - v (B the largest arc
+// minimum); the pixel is a corner on that side at threshold T iff the value exceeds T, and its score is then the larger
+// side's value - 1.  A survivor of the pretest on one side only cannot be a corner on the other side (the other side's
+// value is at most its pretest margin, which did not exceed T), so a corner found on one side alone has that side's score.
+template <int TS, bool DARK>
+__device__ __forceinline__ int fast_side(const uint8_t* t)
+{
+    const int v = t[0];
+    const int p[16] = {t[3 * TS], t[3 * TS + 1], t[2 * TS + 2], t[TS + 3], t[3], t[-TS + 3], t[-2 * TS + 2], t[-3 * TS + 1],
+                       t[-3 * TS], t[-3 * TS - 1], t[-2 * TS - 2], t[-TS - 3], t[-3], t[TS - 3], t[2 * TS - 2], t[3 * TS - 1]};
+    int e3[16], arc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        e3[k] = DARK ? max3_op(p[k], p[(k + 1) & 15], p[(k + 2) & 15]) : min3_op(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)                                                   // ring k..k+8
+        arc[k] = DARK ? max3_op(e3[k], e3[(k + 3) & 15], e3[(k + 6) & 15]) : min3_op(e3[k], e3[(k + 3) & 15], e3[(k + 6) & 15]);
+    return DARK ? v - min16i(arc) : max16i(arc) - v;
+}
+
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 as_s16x2(uint32_t u) { return __builtin_bit_cast(s16x2, u); }
 __device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -511,11 +531,12 @@ __device__ __forceinline__ s16x2 pair16(uint32_t w0, uint32_t w1, uint32_t w2)
 
 // Necessary condition for two horizontally adjacent pixels at once (16-bit packed lanes): an arc of 9
 // ring pixels holds one pixel of every antipodal pair, so a dark corner needs, in each of the four even pairs
-// (0,8) (2,10) (4,12) (6,14), one member below v - t, that is v - max_k min(p_k, p_k+8) > t; a bright corner needs
-// min_k max(p_k, p_k+8) - v > t.  Returns the larger of the two margins per lane; a corner needs > t.
+// (0,8) (2,10) (4,12) (6,14), one member below v - t, that is max_k min(p_k, p_k+8) < v - t; a bright corner needs
+// min_k max(p_k, p_k+8) > v + t.  qd / qb: per lane a value whose sign bit is set exactly when the pixel survives as a
+// dark / bright candidate at threshold t (thr holds t in both lanes).
 template <int J0>
-__device__ __forceinline__ s16x2 fast_pretest(const uint32_t (&m3)[3], const uint32_t (&m2)[3], const uint32_t (&c)[3],
-                                              const uint32_t (&p2)[3], const uint32_t (&p3)[3])
+__device__ __forceinline__ void fast_pretest(const uint32_t (&m3)[3], const uint32_t (&m2)[3], const uint32_t (&c)[3],
+                                             const uint32_t (&p2)[3], const uint32_t (&p3)[3], const s16x2 thr, uint32_t& qd, uint32_t& qb)
 {
     const s16x2 v = pair16<3 + J0>(c[0], c[1], c[2]);
     const s16x2 r0 = pair16<3 + J0>(p3[0], p3[1], p3[2]);    // ( 0,+3)
@@ -528,7 +549,8 @@ __device__ __forceinline__ s16x2 fast_pretest(const uint32_t (&m3)[3], const uin
     const s16x2 r10 = pair16<1 + J0>(m2[0], m2[1], m2[2]);   // (-2,-2)
     const s16x2 hi = pmax(pmax(pmin(r0, r8), pmin(r4, r12)), pmax(pmin(r2, r10), pmin(r6, r14)));
     const s16x2 lo = pmin(pmin(pmax(r0, r8), pmax(r4, r12)), pmin(pmax(r2, r10), pmax(r6, r14)));
-    return pmax(v - hi, lo - v);
+    qd = as_u32(hi - (v - thr));
+    qb = as_u32((v + thr) - lo);
 }
 
 // number of set bits of m below the calling lane
@@ -547,6 +569,15 @@ constexpr GroupsPerRow make_groups_per_row()
 }
 __constant__ const GroupsPerRow kGroupsPerRow = make_groups_per_row();
 
+// Diagnostic build (-DORBX_FAST_STAMPS, tools/fast_stamps.py): wave cycles between the phases of k_fast_cells, one row of
+// eight sums per wavefront; a stamp itself costs about 560 cycles.
+#ifdef ORBX_FAST_STAMPS
+constexpr int kStampWaves = 256 * 1024;
+__device__ uint32_t g_fast_stamps[kStampWaves][8];
+#define FSTAMP(i) do { wave_sync(); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_fast_stamps[stamp_row_][i] += (uint32_t)(t_ - t_prev_); t_prev_ = t_; } while (0)
+#else
+#define FSTAMP(i) do {} while (0)
+#endif
 // What one wavefront needs to know about its cell, in launch order (read with scalar loads: one round trip before the
 // tile can be fetched, where cell list -> cell record -> level record took three).
 struct FastCell {
@@ -591,6 +622,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
     if (!frame_chunk(n_frames, frame, blk)) return;
     if ((int)blk * WPB + wave >= nlist) return;
     const FastCell c = fcells[(int)blk * WPB + wave];
+#ifdef ORBX_FAST_STAMPS
+    const uint32_t stamp_row_ = ((uint32_t)frame * (uint32_t)nlist + blk) % kStampWaves;
+    if (lane < 8) g_fast_stamps[stamp_row_][lane] = 0;
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
     const uint8_t* src = pyr + (unsigned long long)frame * pyr_bytes + c.src;
     uint8_t* tile = s_tile[wave];
     uint8_t* score = s_score[wave];
@@ -609,37 +645,62 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
                 *reinterpret_cast<uint4*>(tile + r * TS + 16 * j) = make_uint4(t.x, t.y, t.z, t.w);
             }
     }
+    FSTAMP(0);
     // pretest lanes: groups of four pixels, gpr per row (<= 15), as many whole rows per round as 64 lanes hold
     const int gpr = (cw + 3) >> 2;
     const int rows_per_round = kGroupsPerRow.rows[gpr];              // 64 / gpr
     const int lrow = (lane * kGroupsPerRow.magic[gpr]) >> 16;        // lane / gpr (exact for lane < 64, gpr <= 15)
     const int g = lane - lrow * gpr;
     const int x = 4 * g;
-    // survivor mask layout: pixel 0, 2 of the lane's four in bits 0, 1 and pixel 1, 3 in bits 16, 17
     const int npx = lrow < rows_per_round ? min(cw - x, 4) : 0;            // pixels of the lane inside the cell
-    const uint32_t colmask = (npx > 0 ? 1u : 0u) | (npx > 1 ? 1u << 16 : 0u) | (npx > 2 ? 2u : 0u) | (npx > 3 ? 2u << 16 : 0u);
     const int qbase = lrow * 64 + x;                                       // list entry of the lane's first pixel in round 0
+    // Survivor bits of a lane: one bit per (pixel of its four, round).  Cells of the small variant take at most eight
+    // rounds, so a byte per pixel holds them (pixel k in byte k); larger cells take up to sixteen, a half-word per pixel.
+    // Round r of R sits at bit kRoundBits - R + r of its field (the fields are shifted right once per round).
+    constexpr bool kSmall = TR <= kSmallCellDim + 6;
+    constexpr int kRoundBits = kSmall ? 8 : 16;
+    static_assert(!kSmall || (kSmallCellDim + (64 / ((kSmallCellDim + 3) / 4)) - 1) / (64 / ((kSmallCellDim + 3) / 4)) < 8, "rounds of a small cell must leave the top bit of a byte free");
+    static_assert(kSmall || (kMaxCellDim + 3) / (64 / ((kMaxCellDim + 3) / 4)) < 16, "rounds of a large cell must leave the top bit of a half-word free");
+    typedef typename std::conditional<kSmall, uint32_t, unsigned long long>::type Bits;
+    const Bits colbits = kSmall ? (Bits)(npx >= 4 ? 0xFFFFFFFFu : (1u << (8 * npx)) - 1u)
+                                : (npx >= 4 ? ~(Bits)0 : ((Bits)1 << (16 * npx)) - (Bits)1);
 
-    // exact scores of queue[0..n): corners (score >= T) go to the score tile and, when LIST, to the front of the queue
-    // (a scored entry is written at or below the slot its lane just read, so no waiting entry is overwritten)
-    auto score_queued = [&](int n, int T, bool list) -> int {
+    // exact two-sided scores of queue[0..n) (dense path): corners (score >= T) go to the score tile
+    auto score_queued = [&](int n, int T) {
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < n) {
+                const int i = queue[e];
+                const int yy = i >> 6, xx = i & 63;
+                const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
+                if (sc >= T) score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
+            }
+        }
+    };
+    // one side's exact value of queue[first .. first + n): corners (value > T) go to the score tile with score value - 1
+    // and are compacted to queue[dst ..), dst <= first (a scored entry is written at or below the slot its lane just
+    // read, so no waiting entry is overwritten); returns their number
+    auto score_side = [&](auto dark, int first, int n, int T, int dst) -> int {
+        constexpr bool DARK = decltype(dark)::value;
         int kept = 0;
         for (int e0 = 0; e0 < n; e0 += 64) {
             const int e = e0 + lane;
             bool keep = false;
             int i = 0;
             if (e < n) {
-                i = queue[e];
+                i = queue[first + e];
                 const int yy = i >> 6, xx = i & 63;
-                const int sc = fast_score<TS>(&tile[(yy + 3) * TS + xx + 3]);
-                keep = sc >= T;
-                if (keep) score[(yy + 1) * SS + xx + 1] = (uint8_t)sc;
+                const int val = fast_side<TS, DARK>(&tile[(yy + 3) * TS + xx + 3]);
+                keep = val > T;
+                if (keep) {
+                    uint8_t* sp = &score[(yy + 1) * SS + xx + 1];
+                    // a pixel that survived on both sides may already hold its dark score
+                    *sp = (uint8_t)(DARK ? val - 1 : max((int)*sp, val - 1));
+                }
             }
-            if (list) {
-                const unsigned long long m = __ballot(keep);
-                if (keep) queue[kept + lanes_below(m)] = (uint16_t)i;
-                kept += __popcll(m);
-            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) queue[dst + kept + lanes_below(m)] = (uint16_t)i;
+            kept += __popcll(m);
         }
         return kept;
     };
@@ -662,17 +723,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
         for (int i = lane; i < ((ch + 2) * SS + 15) >> 4; i += 64) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
         if (lane < MR) rowmask[lane] = 0;
         wave_sync();
-        const s16x2 thr1 = {(short)(T + 1), (short)(T + 1)};
-        // pass 1: every lane keeps the survivors of its four pixels per round as a nibble of its own bit set (round r in bits
-        // 4r..4r+3; nibble bit k is pixel {0, 2, 1, 3}[k] of the group): nothing is queued while the rounds run
-        // (cells of the small variant take at most seven rounds: 32 bits hold them)
-        typedef typename std::conditional<(TR <= kSmallCellDim + 6), uint32_t, unsigned long long>::type Bits;
-        static_assert(TR > kSmallCellDim + 6 || (kSmallCellDim + 5) / (64 / ((kSmallCellDim + 3) / 4)) + 1 <= 8, "rounds of a small cell must fit 32 bits");
-        Bits mybits = 0;
-        int round = 0;
-        for (int y0 = 0; y0 < ch; y0 += rows_per_round, ++round) {
+        FSTAMP(1);
+        const s16x2 thr = {(short)T, (short)T};
+        // pass 1: every lane keeps the survivors of its four pixels per round in its own bit sets, dark and bright
+        // candidates apart: nothing is queued while the rounds run
+        Bits dbits = 0, bbits = 0;
+        uint32_t ad01 = 0, ad23 = 0, ab01 = 0, ab23 = 0;             // large cells: pixels 0,1 / 2,3 as half-words
+        int R = 0;
+        for (int y0 = 0; y0 < ch; y0 += rows_per_round, ++R) {
             const int y = y0 + lrow;
-            if (y < ch && colmask) {
+            if constexpr (kSmall) { dbits >>= 1; bbits >>= 1; }
+            else { ad01 >>= 1; ad23 >>= 1; ab01 >>= 1; ab23 >>= 1; }
+            if (y < ch && npx > 0) {
                 const uint32_t* row = reinterpret_cast<const uint32_t*>(&tile[y * TS]) + g;   // tile row y = image row y-3
                 constexpr int RS = TS / 4;
                 const uint32_t m3[3] = {row[0], row[1], row[2]};
@@ -680,35 +742,55 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
                 const uint32_t cc[3] = {row[3 * RS], row[3 * RS + 1], row[3 * RS + 2]};
                 const uint32_t p2[3] = {row[5 * RS], row[5 * RS + 1], row[5 * RS + 2]};
                 const uint32_t p3[3] = {row[6 * RS], row[6 * RS + 1], row[6 * RS + 2]};
-                // margin - (T + 1) is non-negative (sign bit clear) exactly for the survivors
-                const uint32_t q01 = as_u32(fast_pretest<0>(m3, m2, cc, p2, p3) - thr1);
-                const uint32_t q23 = as_u32(fast_pretest<2>(m3, m2, cc, p2, p3) - thr1);
-                uint32_t pm = (((q01 & 0x80008000u) ^ 0x80008000u) >> 15) | (((q23 & 0x80008000u) ^ 0x80008000u) >> 14);
-                pm &= colmask;
-                mybits |= (Bits)((pm & 3u) | ((pm >> 14) & 0xCu)) << (4 * round);
+                uint32_t qd01, qb01, qd23, qb23;
+                fast_pretest<0>(m3, m2, cc, p2, p3, thr, qd01, qb01);
+                fast_pretest<2>(m3, m2, cc, p2, p3, thr, qd23, qb23);
+                if constexpr (kSmall) {
+                    // the four sign bytes side by side, pixel k in byte k
+                    dbits |= __builtin_amdgcn_perm(qd23, qd01, 0x07050301u) & 0x80808080u;
+                    bbits |= __builtin_amdgcn_perm(qb23, qb01, 0x07050301u) & 0x80808080u;
+                } else {
+                    ad01 |= qd01 & 0x80008000u; ad23 |= qd23 & 0x80008000u;
+                    ab01 |= qb01 & 0x80008000u; ab23 |= qb23 & 0x80008000u;
+                }
             }
         }
-        // the survivors in `bits` go to the queue in one step: a prefix sum of the lanes' counts (incl, of which `mine`
-        // are the lane's own), then every lane writes its own (the order inside the queue does not matter)
-        auto enqueue = [&](Bits bits, int incl, int mine) {
-            int off = incl - mine;
+        if constexpr (!kSmall) {
+            dbits = (Bits)ad01 | ((Bits)ad23 << 32);
+            bbits = (Bits)ab01 | ((Bits)ab23 << 32);
+        }
+        dbits &= colbits; bbits &= colbits;
+        FSTAMP(2);
+        // the survivors in `bits` go to the queue from entry `off` on (the order inside the queue does not matter)
+        const int rstep = rows_per_round * 64;
+        const int qb0 = qbase - (kRoundBits - R) * rstep;
+        auto lowest = [](Bits bits) -> int { return sizeof(Bits) == 4 ? __ffs((int)bits) - 1 : __ffsll((long long)bits) - 1; };
+        auto entry_of = [&](int bpos) -> uint16_t {
+            return (uint16_t)(qb0 + (int)__umul24((uint32_t)(bpos & (kRoundBits - 1)), (uint32_t)rstep) + (bpos >> (kSmall ? 3 : 4)));
+        };
+        auto enqueue = [&](Bits bits, int off) {
             while (bits) {
-                const int bpos = sizeof(Bits) == 4 ? __ffs((int)bits) - 1 : __ffsll((long long)bits) - 1;
+                queue[off++] = entry_of(lowest(bits));
                 bits &= bits - 1;
-                const int k = bpos & 3;
-                queue[off++] = (uint16_t)(qbase + (bpos >> 2) * (rows_per_round * 64) + (((k & 1) << 1) | (k >> 1)));
             }
         };
-        const int mine = __popcll((unsigned long long)mybits);
-        const int incl = ot_wave_scan_incl(mine);
-        const int nq = __builtin_amdgcn_readlane(incl, 63);
-        dense = nq > QCAP;
+        // one prefix sum for both lists: dark counts in the low half, bright counts in the high half
+        const int mine_d = __popcll((unsigned long long)dbits), mine_b = __popcll((unsigned long long)bbits);
+        const int incl = ot_wave_scan_incl(mine_d | (mine_b << 16));
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        const int nd = tot & 0xFFFF, nb = tot >> 16;
+        dense = nd + nb > QCAP;
         if (!dense) {
-            enqueue(mybits, incl, mine);
+            enqueue(dbits, (incl & 0xFFFF) - mine_d);
+            enqueue(bbits, nd + (incl >> 16) - mine_b);
             wave_sync();
-            // pass 2: exact score of the queued survivors
-            nsq = score_queued(nq, T, true);
+            FSTAMP(3);
+            // pass 2: exact value of the queued survivors, one side per list; the corners end up in queue[0..nsq)
+            const int kd = score_side(std::true_type{}, 0, nd, T, 0);
             wave_sync();
+            nsq = kd + score_side(std::false_type{}, nd, nb, T, kd);
+            wave_sync();
+            FSTAMP(4);
             // pass 3: strict local maxima inside the cell among the corners, one lane per corner; row masks of the maxima
             for (int e = lane; e < nsq; e += 64) {
                 const int i = queue[e];
@@ -716,15 +798,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
                 if (strict_max(yy, xx)) atomicOr(&rowmask[yy], 1ull << xx);
             }
         } else {
-            // more survivors than the list holds: one round (at most 256 of them) at a time, scores only
-            for (int r = 0; r < round; ++r) {
-                const Bits rb = mybits & ((Bits)0xF << (4 * r));
+            // more survivors than the list holds: one round (at most 256 of them) at a time, both sides, scores only
+            const Bits ubits = dbits | bbits;
+            Bits rsel = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rsel |= (Bits)1 << (kRoundBits * k);
+            for (int r = 0; r < R; ++r) {
+                const Bits rb = ubits & (rsel << (kRoundBits - R + r));
                 const int rmine = __popcll((unsigned long long)rb);
                 const int rincl = ot_wave_scan_incl(rmine);
                 const int n = __builtin_amdgcn_readlane(rincl, 63);
-                enqueue(rb, rincl, rmine);
+                enqueue(rb, rincl - rmine);
                 wave_sync();
-                score_queued(n, T, false);
+                score_queued(n, T);
                 wave_sync();
             }
             for (int i = lane; i < cw * ch; i += 64) {
@@ -733,6 +819,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
             }
         }
         wave_sync();
+        FSTAMP(5);
         mask = lane < MR ? rowmask[lane] : 0ull;                      // lane r owns row r (rows >= ch are empty)
         if (__any(mask != 0ull) || max(minTh, 1) >= T) break;         // a second attempt at a threshold not below T finds nothing new
         wave_sync();
@@ -762,6 +849,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
             for (int i = lane; i < cw * ch; i += 64) { const int yy = i / cw; emit(yy, i - yy * cw); }
     }
     if (lane == 0) cellcnt[(unsigned long long)frame * ncells + c.cell] = (uint16_t)min(total, (int)c.cap);
+    FSTAMP(6);
+    FSTAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1649,6 +1738,21 @@ template <typename F> static void parallel_rows(int n, F fn)
 
 extern "C" {
 
+#ifdef ORBX_FAST_STAMPS
+int orbx_debug_fast_stamps(unsigned long long* out16)
+{
+    // sums of the per-wave rows over the first out16[15] rows (the waves of the last launch)
+    const size_t rows = (size_t)out16[15];
+    std::vector<uint32_t> h(rows * 8);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_fast_stamps), h.size() * 4));
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    for (size_t r = 0; r < rows; ++r) for (int i = 0; i < 8; ++i) out16[i] += h[r * 8 + i];
+    out16[15] = rows;
+    return ORBX_OK;
+}
+#endif
+
 int orbx_extractor_create(const orbx_params* p, int width, int height, int max_batch, int device, orbx_extractor** out)
 {
     if (!p || !out || max_batch < 1) { set_error("orbx_extractor_create: bad argument"); return ORBX_ERR_BAD_ARG; }
@@ -1818,7 +1922,11 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     {
         const DevLevel& L0 = ex->hlv[0];
         dim3 grid(frame_chunk_grid((L0.cpr * L0.h + 255) / 256, B));
-        if (ex->channels == 1)
+        if (ex->channels == 1 && d_images == pyr + L0.roi && row_stride == (ptrdiff_t)L0.stride && frame_stride == (ptrdiff_t)G.pyr_bytes) {
+            // the frames already lie where level 0 lives (orbx_extractor_input_view): no copy, only the REFLECT_101 frame
+            dim3 gb((border_threads(L0.w, L0.h, L0.stride, kFrameFill, 1, 2) + 255) / 256, 1, B);
+            hipLaunchKernelGGL(k_borders, gb, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, kFrameFill, 1, 2);
+        } else if (ex->channels == 1)
             hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
                                pyr, (unsigned long long)G.pyr_bytes, L0, B);
         else if (ex->channels == 3)
@@ -2121,6 +2229,16 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* image, ptrdiff_t stride, orb
     int rc = orbx_extract_batch(ex, image, stride, 0, 1, kps, desc, &count, cap);
     *n = count;
     return rc;
+}
+
+int orbx_extractor_input_view(orbx_extractor* ex, uint8_t** d_images, ptrdiff_t* row_stride, ptrdiff_t* frame_stride)
+{
+    if (!ex || !d_images || !row_stride || !frame_stride) { set_error("orbx_extractor_input_view: null pointer"); return ORBX_ERR_BAD_ARG; }
+    const LevelGeom& L = ex->geo.lv[0];
+    *d_images = ex->d_pyr + L.roi;
+    *row_stride = (ptrdiff_t)L.stride;
+    *frame_stride = (ptrdiff_t)ex->geo.pyr_bytes;
+    return ORBX_OK;
 }
 
 int orbx_pyramid_level_device(orbx_extractor* ex, int frame, int level, const uint8_t** d_roi, int* w, int* h, ptrdiff_t* stride)
