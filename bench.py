@@ -383,17 +383,104 @@ def leg_hamming(cx, vsa, np, a, steps, warmup):
 
     t = cx.timed(step, steps, warmup)
     res = (merged if cx.dist is not None else part).cpu().numpy()
+    # how much of the multiplied work also walked its keys (the data-dependent part of the kernel), on this rank
+    m.best2_tile_walks(reset=True)
+    m.hamming_best2_device(q.data_ptr(), nq, table.data_ptr(), rows, c0 * chunk_rows, part.data_ptr(), stream)
+    walked_frac = m.best2_tile_walks() / (((rows + 15) // 16) * ((nq + 15) // 16))
+    # the legs of a multi-GPU step one by one (events on the stream; separate steps, so their sum need not equal a step)
+    legs = None
+    if cx.dist is not None:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        acc = [0.0, 0.0, 0.0]
+        reps = 5
+        for _ in range(reps):
+            cx.barrier()
+            ev[0].record()
+            m.hamming_best2_device(q.data_ptr(), nq, table.data_ptr(), rows, c0 * chunk_rows, part.data_ptr(), stream)
+            ev[1].record()
+            cx.dist.all_gather_into_tensor(gathered, part)
+            ev[2].record()
+            m.best2_merge_device(gathered.data_ptr(), cx.world, nq, merged.data_ptr(), stream)
+            ev[3].record()
+            torch.cuda.synchronize()
+            for k in range(3):
+                acc[k] += ev[k].elapsed_time(ev[k + 1])
+        legs = {"search_ms": round(cx.max_over_ranks(acc[0] / reps), 4), "allgather_ms": round(cx.max_over_ranks(acc[1] / reps), 4),
+                "merge_ms": round(cx.max_over_ranks(acc[2] / reps), 4),
+                "note": "max over ranks of each leg, events on the stream; the all-gather moves 16 bytes per query per rank and "
+                        "includes the wait for the slowest rank's search"}
     m.close()
     pps = float(nq) * total * steps / t
     return {"metric": "Hamming pair-comparisons/s", "value": pps, "queries_per_s": nq * steps / t, "ms_per_step": 1e3 * t / steps,
             "steps": steps, "queries": nq, "map_rows_total": total, "map_rows_per_gpu": rows, "scaling": "strong",
             "collective": None if cx.dist is None else "all_gather_into_tensor of 16-byte top-2 records + k_best2_merge",
+            "legs": legs, "tiles_walked_frac": round(walked_frac, 6), "data": "iid uniform 256-bit rows, queries = rows with ~8 % of the bits flipped",
             "matched_within_50": int((res[:, 0] <= 50).sum()),
             # the search runs on the matrix cores as an exact int8 contraction; popcount_frac prices the same pairs
             # against the vector pipe's xor / popcount issue peak (above 1: more than that formulation can reach)
             "roofline": {"bound": "mfma", "achieved": round(MFMA_OPS_PER_PAIR * pps / cx.world / 1e12, 1),
                          "peak": MFMA_I8_PEAK / 1e12, "unit": "TOP/s",
                          "frac": round(MFMA_OPS_PER_PAIR * pps / cx.world / MFMA_I8_PEAK, 4),
+                         "popcount_frac": round(OPS_PER_PAIR * pps / cx.world / VALU_PEAK, 4)}}
+
+
+def leg_hamming_extracted(cx, vsa, np, steps, warmup, n_map_frames=256, W=1241, H=376, nfeatures=2000, nq=4096):
+    """The same brute-force search on descriptors the extractor itself produced: the map is every descriptor of
+    n_map_frames different synthetic 1241x376 frames, the queries are descriptors of other frames.  Real descriptors are
+    not uniform (bits correlate, frames repeat structure), so more tiles walk their keys than on the iid map."""
+    torch = cx.torch
+    p = vsa.make_params(nfeatures=nfeatures, nlevels=8)
+    n_q_frames = 4
+    chunk = 64
+    ex = vsa.Extractor(p, W, H, max_batch=chunk, device=cx.local)
+    cap = ex.cap
+    stream = torch.cuda.current_stream().cuda_stream
+    rows, qrows = [], []
+    kps = torch.zeros((chunk, cap, 7), dtype=torch.float32, device=cx.dev)
+    desc = torch.zeros((chunk, cap, 32), dtype=torch.uint8, device=cx.dev)
+    counts = torch.zeros(chunk, dtype=torch.int32, device=cx.dev)
+    seed0 = 700000 + cx.rank * 10000
+    total_frames = n_map_frames + n_q_frames
+    for f0 in range(0, total_frames, chunk):
+        nf = min(chunk, total_frames - f0)
+        frames = torch.from_numpy(np.stack([vsa.synth_frame(seed0 + f0 + i, W, H) for i in range(nf)])).to(cx.dev)
+        ex.extract_batch_device(frames.data_ptr(), W, W * H, nf, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+        torch.cuda.synchronize()
+        cn = counts.cpu().numpy()
+        for i in range(nf):
+            (rows if f0 + i < n_map_frames else qrows).append(desc[i, :int(cn[i])].clone())
+    ex.close()
+    table = torch.cat(rows).contiguous()
+    q = torch.cat(qrows)[:nq].contiguous()
+    nt, nq = table.shape[0], q.shape[0]
+    m = vsa.Matcher(device=cx.local)
+    out = torch.zeros((nq, 4), dtype=torch.int32, device=cx.dev)
+
+    def step():
+        m.hamming_best2_device(q.data_ptr(), nq, table.data_ptr(), nt, 0, out.data_ptr(), stream)
+
+    t = cx.timed(step, steps, warmup)
+    m.best2_tile_walks(reset=True)
+    step()
+    walked_frac = m.best2_tile_walks() / (((nt + 15) // 16) * ((nq + 15) // 16))
+    res = out.cpu().numpy()
+    # like for like: an iid-uniform map of the same number of rows (a map this small amortises the kernel's start-up
+    # less than the 2^24-row one), queries noisy copies of its rows
+    u_np = vsa.synth_descriptors(4242, nt)
+    uq_np, _ = vsa.synth_queries(4343, u_np, nq)
+    table.copy_(torch.from_numpy(u_np))
+    q.copy_(torch.from_numpy(uq_np))
+    t_uniform = cx.timed(step, steps, warmup)
+    m.close()
+    pps = cx.world * float(nq) * nt * steps / t
+    return {"metric": "Hamming pair-comparisons/s on extracted descriptors", "value": pps, "ms_per_step": 1e3 * t / steps, "steps": steps,
+            "uniform_map_of_the_same_size_value": cx.world * float(nq) * nt * steps / t_uniform,
+            "queries": nq, "map_rows_per_gpu": nt, "scaling": "weak",
+            "data": f"map = all descriptors of {n_map_frames} different synthetic {W}x{H} frames ({nfeatures} features), queries = descriptors of "
+                    f"{n_q_frames} other frames; one map per GPU",
+            "tiles_walked_frac": round(walked_frac, 6), "median_best": int(np.median(res[:, 0])), "median_second": int(np.median(res[:, 2])),
+            "roofline": {"bound": "mfma", "achieved": round(MFMA_OPS_PER_PAIR * pps / cx.world / 1e12, 1), "peak": MFMA_I8_PEAK / 1e12,
+                         "unit": "TOP/s", "frac": round(MFMA_OPS_PER_PAIR * pps / cx.world / MFMA_I8_PEAK, 4),
                          "popcount_frac": round(OPS_PER_PAIR * pps / cx.world / VALU_PEAK, 4)}}
 
 
@@ -423,9 +510,17 @@ def dry_worker(cx, a):
         gathered.copy_(mine)
     merged = vsa.best2_merge(gathered.numpy().view(vsa.BEST2_DTYPE).reshape(cx.world, nq))
     frames = cx.sum_over_ranks(fe - fb)
+    ranges = torch.tensor([fb, fe, c0, c1], dtype=torch.int64)
+    all_ranges = torch.zeros(cx.world * 4, dtype=torch.int64)
+    if cx.dist is not None:
+        cx.dist.all_gather_into_tensor(all_ranges, ranges)
+    else:
+        all_ranges.copy_(ranges)
+    all_ranges = all_ranges.reshape(cx.world, 4).tolist()
     if cx.rank == 0:
         print(json.dumps({"dry": True, "n_gpus": cx.world, "ranks_seen": seen, "frames_covered": int(frames),
-                          "frame_range_rank0": [fb, fe], "map_chunks_rank0": [c0, c1], "merge": "orbx_best2_merge",
+                          "frame_range_rank0": [fb, fe], "map_chunks_rank0": [c0, c1],
+                          "frame_ranges": [r[:2] for r in all_ranges], "map_chunk_ranges": [r[2:] for r in all_ranges], "merge": "orbx_best2_merge",
                           "merged_best_sum": int(merged["best"].sum()), "merged_idx_sum": int(merged["best_idx"].sum()),
                           "merged_second_sum": int(merged["second"].sum()), "backend": "gloo"}))
     if cx.dist is not None:
@@ -536,6 +631,8 @@ def worker(a):
     hamming = None
     if not a.no_hamming:
         hamming = leg_hamming(cx, vsa, np, a, max(2, min(a.steps, 40)), min(a.warmup, 3))
+        torch.cuda.empty_cache()
+        hamming["extracted_descriptors"] = leg_hamming_extracted(cx, vsa, np, max(2, min(a.steps, 40)), min(a.warmup, 3))
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     cpu = None

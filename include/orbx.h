@@ -105,7 +105,10 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, ptrdiff_t row_
 /* Device-resident batch: images, keypoints, descriptors and counts all in HBM; asynchronous, on `stream`.  The calls
  * that read the context's state of the last batch afterwards (orbx_pyramid_level(s), the orbx_debug_* taps,
  * orbx_stereo_refine_batch_device on any stream) order themselves behind it through an event the batch records: the
- * caller needs no synchronisation of its own for them, only for its own reads of the output arrays. */
+ * caller needs no synchronisation of its own for them, only for its own reads of the output arrays.  That guarantee
+ * holds for batches issued outside stream capture, one stream at a time per context: a batch recorded into the caller's
+ * own graph records no event (it would become a node of that graph), and after replaying such a graph, or after
+ * issuing batches of one context on several streams, the caller synchronises before those calls itself. */
 int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdiff_t row_stride,
                               ptrdiff_t frame_stride, int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc,
                               int32_t* d_counts, int cap_per_frame, void* stream);
@@ -196,14 +199,23 @@ void orbx_compute_three_maxima(const int32_t* sizes, int L, int* ind1, int* ind2
 int orbx_hamming_best2(orbx_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int64_t nt, orbx_best2* out);
 int orbx_hamming_best2_device(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
                               int64_t index_base, orbx_best2* d_out, void* stream);
+/* Measurement tap (no counterpart in the reference): the brute-force kernel multiplies every tile of 16 rows x 16 queries
+ * on the matrix cores but walks a tile's keys only when one of its distances can still change a result, so its speed
+ * depends on the data.  *walked = tiles walked on the matcher's GPU since the last reset, over all calls of the process
+ * on that GPU (synchronises the device); the tiles multiplied are ceil(rows / 16) x ceil(queries / 16) per call. */
+int orbx_debug_best2_tile_walks(orbx_matcher* m, uint64_t* walked, int reset);
 /* No counterpart in the reference.  orbx_hamming_best2_device for callers that cannot allocate device memory: code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same results; the kernels'
  * scratch (per-run partial results and the seed records of the two-pass search) is a fixed array in the library's device
  * image (4 MiB + 256 KiB, held by every GPU the library runs on for the life of the process) whose address on the matcher's
  * device was resolved at orbx_matcher_create.  The call itself makes no hipMalloc / hipFree.  Limits: nq <= 16384 and
  * orbx_hamming_best2_workspace_bytes(nq, nt) - 16 * nq <= 4 MiB (the row-run split keeps this near 2 MiB for every map
- * size at nq <= 16384; e.g. 4096 x 2^24 fits); beyond them ORBX_ERR_CAPACITY.  All calls on one GPU share the array, whichever matcher they
- * go through: calls that overlap in time on one GPU race (also with different streams); serialise them. */
+ * size at nq <= 16384; e.g. 4096 x 2^24 fits); beyond them ORBX_ERR_CAPACITY.  All calls on one GPU share the array, whichever matcher
+ * they go through.  Outside stream capture the library orders them itself: every call waits (on its stream) for an event
+ * that the previous call on that GPU recorded behind its kernels, so calls from several matchers, streams and host threads
+ * run one after the other instead of racing.  A call issued while its stream is being captured takes no part in that
+ * (an event wait would become a node of the caller's graph): captured calls, and replays of graphs that hold them, must
+ * not overlap with other users of the array on the same GPU -- that ordering stays the caller's. */
 int orbx_hamming_best2_device_static(orbx_matcher* m, const uint8_t* d_q, int nq, const uint8_t* d_t, int64_t nt,
                                      int64_t index_base, orbx_best2* d_out, void* stream);
 /* Merge per-shard results (ranks x nq records, shard-major; best_idx already global) into nq records:

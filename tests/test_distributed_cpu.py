@@ -112,6 +112,16 @@ def test_bench_launcher_spawns_ranks_itself():
     assert out["merged_second_sum"] == int(ms.sum())
 
 
+def test_bench_launcher_eight_ranks():
+    """The shape the scaling record is taken at: eight ranks, every rank seen by the collective, the 4096-frame batch
+    covered once by contiguous ranges, one map chunk per rank."""
+    out = _run_bench(["--gpus", "8", "--dry", "--backend", "gloo"])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == list(range(8)) and out["launcher"]["spawned"] == 8
+    assert out["frames_covered"] == 4096
+    assert out["frame_ranges"] == [[512 * r, 512 * (r + 1)] for r in range(8)]
+    assert out["map_chunk_ranges"] == [[r, r + 1] for r in range(8)]
+
+
 def test_bench_single_rank_needs_no_launcher():
     out = _run_bench(["--gpus", "1", "--dry"])
     assert out["n_gpus"] == 1 and out["ranks_seen"] == [0] and "launcher" not in out

@@ -47,7 +47,7 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
     w, h = 640, 480
     im1 = vsa.synth_frame(12, w, h)
     im2 = np.roll(im1, (3, 5), axis=(0, 1))
-    oex = oracle.Extractor(oracle.make_params(2000))
+    oex = oracle.Extractor(oracle.make_params(2000, trig_mode=1))
     ok1, od1 = oex.extract(im1)
     want_pyr3 = oex.level_padded(3)
     ok2, od2 = oex.extract(im2)
@@ -71,7 +71,7 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
     # Frame::ComputeStereoMatches through ORBmatcher::ComputeStereoMatches (two extractor instances)
     sw, sh = 752, 480
     left, right = vsa.synth_stereo(31, sw, sh)
-    oexl, oexr = oracle.Extractor(oracle.make_params(1200)), oracle.Extractor(oracle.make_params(1200))
+    oexl, oexr = oracle.Extractor(oracle.make_params(1200, trig_mode=1)), oracle.Extractor(oracle.make_params(1200, trig_mode=1))
     kl, dl = oexl.extract(left); kr, dr = oexr.extract(right)
     assert nL == len(kl) and nR == len(kr)
     bf = np.float32(47.90639384423901); fx = np.float32(435.2046959714599)
@@ -97,5 +97,5 @@ def test_cpp_dropin_classes(vsa, oracle, tmp_path):
 
     # BGR frame through ORBextractor::SetInputFormat(ORBX_INPUT_BGR)
     bgr = np.stack([vsa.synth_frame(70 + c, w, h) for c in range(3)], axis=2)
-    okc, odc = oracle.Extractor(oracle.make_params(1000)).extract(oracle.cvt_color_to_gray(bgr, blue_first=True))
+    okc, odc = oracle.Extractor(oracle.make_params(1000, trig_mode=1)).extract(oracle.cvt_color_to_gray(bgr, blue_first=True))
     assert n_c == len(okc) and np.array_equal(k_c, okc.astype(vsa.KEYPOINT_DTYPE)) and np.array_equal(d_c, odc)

@@ -553,3 +553,11 @@ def test_input_view_skips_the_copy_and_changes_nothing(vsa, oracle):
         assert np.array_equal(d1[f, :c1[f]], odesc)
         assert np.array_equal(l1[f][0], oex.level_padded(0))
     ex.close()
+
+
+def test_geometry_beyond_the_launch_grid_is_refused_at_create(vsa):
+    """More FAST cells per frame than a launch grid's second dimension holds (65535): refused when the context is
+    created, with a message that names the stage, not at the first extraction with a bare HIP error."""
+    with pytest.raises(vsa.OrbxError) as e:
+        vsa.Extractor(vsa.make_params(20000, 1.1, 16, 20, 7), 4096, 4096, max_batch=1, device=0)
+    assert e.value.status == 2 and "workgroups per frame" in str(e.value), str(e.value)

@@ -129,7 +129,7 @@ def test_best2_large_property(vsa, oracle, matcher):
 def test_best2_full_size_and_sharded(vsa, oracle, matcher):
     """The map-matching workload at full size (4096 queries x 2^24 rows, 512 MiB of descriptors) in one pass, and the
     same map cut into 8 contiguous shards whose results are merged the way the ranks of a multi-GPU run merge theirs:
-    both must agree exactly; planted rows are found; two queries are checked against the oracle."""
+    both must agree exactly; planted rows are found; 64 queries are checked against the oracle."""
     import torch
     nt, nq, shards = 1 << 24, 4096, 8
     table = vsa.synth_descriptors(42, nt)
@@ -148,8 +148,13 @@ def test_best2_full_size_and_sharded(vsa, oracle, matcher):
     w = whole.cpu().numpy(); mg = merged.cpu().numpy()
     assert np.array_equal(w[:, :3], mg[:, :3])
     assert (w[:, 1] == src).mean() > 0.99 and (w[:, 2] >= w[:, 0]).all()
-    want = oracle.hamming_best2(q[:2], table)
-    assert np.array_equal(w[:2, 0], want["best"]) and np.array_equal(w[:2, 1], want["best_idx"]) and np.array_equal(w[:2, 2], want["second"])
+    # 64 queries against the oracle over the whole map: every position n of a 16-query tile four times, every one of the
+    # eight query tiles of a workgroup, spread over the 32 workgroup rows of the grid (every query meets all four lane
+    # groups, which hold different rows of the same queries)
+    pick = np.array([((j * 5) % 32) * 128 + ((j // 3) % 8) * 16 + (j % 16) for j in range(64)])
+    assert len(set(pick.tolist())) == 64 and set((pick % 16).tolist()) == set(range(16)) and set(((pick % 128) // 16).tolist()) == set(range(8))
+    want = oracle.hamming_best2(np.ascontiguousarray(q[pick]), table)
+    assert np.array_equal(w[pick, 0], want["best"]) and np.array_equal(w[pick, 1], want["best_idx"]) and np.array_equal(w[pick, 2], want["second"])
 
 
 def test_csr_distances(vsa, oracle, matcher):

@@ -61,3 +61,62 @@ def test_static_scratch_rejects_oversized_requests():
         m.hamming_best2_device_static(q.data_ptr(), nq, t.data_ptr(), 4096, 0, out.data_ptr(), None)
     assert e.value.status == 4 and "fixed scratch" in str(e.value)
     m.close()
+
+
+def test_static_scratch_calls_from_two_matchers_and_streams_do_not_race():
+    """Two matchers, two streams, interleaved calls with different inputs: the calls share one scratch per GPU and the
+    library orders them behind each other; every result equals the allocating entry point's."""
+    import torch
+    dev = torch.device("cuda:0")
+    ma, mb = vsa.Matcher(device=0), vsa.Matcher(device=0)
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    jobs = []
+    for k in range(6):
+        t_np = vsa.synth_descriptors(100 + k, (1 << 18) + 64 * k if k % 2 == 0 else 20000 + 1000 * k)
+        q_np, _ = vsa.synth_queries(200 + k, t_np, 700 + 100 * k)
+        q, t = torch.from_numpy(q_np).to(dev), torch.from_numpy(t_np).to(dev)
+        ref = torch.zeros((q_np.shape[0], 4), dtype=torch.int32, device=dev)
+        got = torch.zeros_like(ref)
+        ma.hamming_best2_device(q.data_ptr(), q_np.shape[0], t.data_ptr(), t_np.shape[0], 0, ref.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        jobs.append((q, t, ref, got))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k, (q, t, ref, got) in enumerate(jobs):
+            m, s = (ma, sa) if k % 2 == 0 else (mb, sb)
+            m.hamming_best2_device_static(q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0], 0, got.data_ptr(), s.cuda_stream)
+    torch.cuda.synchronize()
+    for q, t, ref, got in jobs:
+        assert torch.equal(ref, got)
+    ma.close(); mb.close()
+
+
+def test_static_scratch_under_graph_capture_and_replay():
+    """The use the entry point exists for: the call is captured into a HIP graph (nothing in it allocates) and the graph
+    is replayed on new query data."""
+    import torch
+    dev = torch.device("cuda:0")
+    m = vsa.Matcher(device=0)
+    t_np = vsa.synth_descriptors(11, 50000)
+    qa_np, _ = vsa.synth_queries(12, t_np, 512)
+    qb_np, _ = vsa.synth_queries(13, t_np, 512)
+    t = torch.from_numpy(t_np).to(dev)
+    q = torch.from_numpy(qa_np).to(dev)
+    got = torch.zeros((512, 4), dtype=torch.int32, device=dev)
+    ref = torch.zeros_like(got)
+    s = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        m.hamming_best2_device_static(q.data_ptr(), 512, t.data_ptr(), 50000, 0, got.data_ptr(), s.cuda_stream)    # warm, uncaptured
+        s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            m.hamming_best2_device_static(q.data_ptr(), 512, t.data_ptr(), 50000, 0, got.data_ptr(), s.cuda_stream)
+    for q_np in (qa_np, qb_np):
+        q.copy_(torch.from_numpy(q_np).to(dev))
+        got.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        m.hamming_best2_device(q.data_ptr(), 512, t.data_ptr(), 50000, 0, ref.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(ref, got)
+    m.close()

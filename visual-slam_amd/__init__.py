@@ -97,6 +97,7 @@ _SIGS = {
     "orbx_hamming_best2": (_i, [_vp, _vp, _i, _vp, _i64, _vp]),
     "orbx_hamming_best2_device": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _vp, _vp]),
     "orbx_hamming_best2_device_static": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _vp, _vp]),
+    "orbx_debug_best2_tile_walks": (_i, [_vp, C.POINTER(C.c_uint64), _i]),
     "orbx_best2_merge_device": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "orbx_best2_merge": (_i, [_vp, _i, _i, _vp]),
     "orbx_hamming_best2_workspace_bytes": (_i64, [_i, _i64]),
@@ -426,6 +427,12 @@ class Matcher:
 
     def hamming_best2_device(self, d_q, nq, d_t, nt, index_base, d_out, stream=None):
         _check(lib.orbx_hamming_best2_device(self.h, d_q, nq, d_t, nt, index_base, d_out, stream))
+
+    def best2_tile_walks(self, reset=True):
+        """Tiles of 16 rows x 16 queries whose keys the brute-force kernel walked on this GPU since the last reset."""
+        v = C.c_uint64(0)
+        _check(lib.orbx_debug_best2_tile_walks(self.h, C.byref(v), 1 if reset else 0))
+        return int(v.value)
 
     def hamming_best2_device_static(self, d_q, nq, d_t, nt, index_base, d_out, stream=None):
         """The variant that allocates nothing (fixed device scratch)."""

@@ -17,7 +17,9 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST)
 {
     mParams.nfeatures = _nfeatures; mParams.scale_factor = _scaleFactor; mParams.nlevels = _nlevels;
-    mParams.ini_th_fast = _iniThFAST; mParams.min_th_fast = _minThFAST; mParams.blur_rounding = 0; mParams.trig_mode = 0;
+    mParams.ini_th_fast = _iniThFAST; mParams.min_th_fast = _minThFAST; mParams.blur_rounding = 0;
+    // cos / sin as the reference's own callee computes them: glibc's cosf / sinf (src/ORBextractor.cc:111-112), bit for bit
+    mParams.trig_mode = 1;
     mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
     mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     mnFeaturesPerLevel.resize(nlevels); umax.resize(16);

@@ -48,7 +48,7 @@ public:
     // grey conversion Tracking::GrabImage* does on the host (src/Tracking.cc:254-267), so that call site can drop its cvtColor.
     void SetInputFormat(int format);
     void SetBlurRounding(int mode);
-    // cos / sin of the keypoint angle (orbx_params::trig_mode): 0 correctly rounded, 1 / 2 glibc's cosf / sinf bit for bit
+    // cos / sin of the keypoint angle (orbx_params::trig_mode): 1 (default) / 2 glibc's cosf / sinf bit for bit, 0 correctly rounded
     // (what src/ORBextractor.cc:112 calls on a glibc system)
     void SetTrigMode(int mode);
     // Frame::UndistortKeyPoints (src/Frame.cc:404-434) for the keypoints of the last operator() call's image size:

@@ -28,8 +28,12 @@
 #include "MapPoint.h"
 
 #include <climits>
+#include <cmath>
 #include <list>
+#include <map>
+#include <memory>
 #include <set>
+#include <utility>
 #include <vector>
 
 using namespace std;

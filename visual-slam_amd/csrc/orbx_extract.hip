@@ -578,6 +578,10 @@ __device__ uint32_t g_fast_stamps[kStampWaves][8];
 #else
 #define FSTAMP(i) do {} while (0)
 #endif
+#ifndef ORBX_FAST_WPE_MIN
+#define ORBX_FAST_WPE_MIN 7
+#define ORBX_FAST_WPE_MAX 8
+#endif
 // What one wavefront needs to know about its cell, in launch order (read with scalar loads: one round trip before the
 // tile can be fetched, where cell list -> cell record -> level record took three).
 struct FastCell {
@@ -603,7 +607,7 @@ struct FastCell {
 // the worst one.  A cell with more survivors than the list holds takes the dense path: its rounds are queued and
 // scored one at a time, no corner list is kept, and passes 3 and the emission walk all pixels of the cell instead.
 template <int TS, int TR, int SS, int SR, int MR, int QCAP, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= kSmallCellDim + 6 ? 7 : 3, 8))) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= kSmallCellDim + 6 ? ORBX_FAST_WPE_MIN : 3, TR <= kSmallCellDim + 6 ? ORBX_FAST_WPE_MAX : 8))) void k_fast_cells(const uint8_t* __restrict__ pyr, unsigned long long pyr_bytes,
                                                     const FastCell* __restrict__ fcells, int nlist,
                                                     uint32_t* __restrict__ cand, int cand_total,
                                                     uint16_t* __restrict__ cellcnt, int ncells,
@@ -1755,7 +1759,7 @@ int orbx_debug_fast_stamps(unsigned long long* out16)
 
 int orbx_extractor_create(const orbx_params* p, int width, int height, int max_batch, int device, orbx_extractor** out)
 {
-    if (!p || !out || max_batch < 1) { set_error("orbx_extractor_create: bad argument"); return ORBX_ERR_BAD_ARG; }
+    if (!p || !out || max_batch < 1 || max_batch > 65535) { set_error("orbx_extractor_create: bad argument (max_batch must be 1..65535)"); return ORBX_ERR_BAD_ARG; }
     *out = nullptr;
     Geometry geo;
     int rc = build_geometry(*p, width, height, geo);
@@ -1856,6 +1860,24 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         }
         HIP_CHECK(hipMalloc(&ex->d_fast_cells, sizeof(FastCell) * fc.size()));
         HIP_CHECK(hipMemcpy(ex->d_fast_cells, fc.data(), sizeof(FastCell) * fc.size(), hipMemcpyHostToDevice));
+    }
+    {
+        // every per-frame grid puts its chunk count into gridDim.y (at most 65535): refuse here, by name, what a launch
+        // would otherwise refuse later with a bare HIP error
+        long worst = 0; const char* which = "";
+        auto see = [&](long chunks, const char* name) { if (chunks > worst) { worst = chunks; which = name; } };
+        see(((long)ex->hlv[0].cpr * ex->hlv[0].h + 255) / 256, "level-0 copy");
+        for (int l = 1; l < geo.nlevels; ++l)
+            see(((long)ex->hlv[l].gpr * ((ex->hlv[l].h + kResizeRows - 1) / kResizeRows) + 255) / 256, "resize");
+        see((ex->n_small + kFastWavesPerBlock - 1) / kFastWavesPerBlock, "FAST cells");
+        see((ex->n_big + kFastWavesPerBlock - 1) / kFastWavesPerBlock, "FAST cells");
+        see((long)((ex->max_blur_threads + 255) / 256) * geo.nlevels, "blur");
+        see((geo.kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), "describe");
+        if (worst > 65535) {
+            set_error(std::string("image too large for this parameter set: the ") + which + " stage needs " + std::to_string(worst) +
+                      " workgroups per frame, the launch grid holds 65535");
+            return ORBX_ERR_UNSUPPORTED_GEOMETRY;
+        }
     }
     if (!geo.rx.empty()) HIP_CHECK(hipMemcpy(ex->d_rx, geo.rx.data(), sizeof(ResizeX) * geo.rx.size(), hipMemcpyHostToDevice));
     if (!geo.ry.empty()) HIP_CHECK(hipMemcpy(ex->d_ry, geo.ry.data(), sizeof(ResizeY) * geo.ry.size(), hipMemcpyHostToDevice));

@@ -6,6 +6,7 @@
 // search against a large map is the one dense contraction of the library (every query against every row): it runs on
 // the matrix cores as an exact int8 product (k_best2_mfma below).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <cstring>
 #include <cmath>
 #include <vector>
@@ -62,6 +63,10 @@ template <int HALF> __device__ __forceinline__ v4i bits16_to_bytes(uint32_t w)  
     return a;
 }
 
+// How data-dependent the search is: tiles of 16 rows x 16 queries whose keys were walked (counted in a scalar register,
+// added once per wavefront), for orbx_debug_best2_tile_walks.
+__device__ unsigned long long g_best2_walked;
+
 // grid: (ceil(nchunks / 4), query tiles of kMfmaQueries); wave w of block x owns chunk 4 x + w
 __global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ t, long long nt,
                                                           int rows_per_chunk, int nchunks, const orbx_best2* __restrict__ seed,
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __rest
     const uint32_t* rows = t + (size_t)r0 * 8 + 2 * grp;
     auto row_at = [&](int r) __attribute__((always_inline)) { return *reinterpret_cast<const uint2*>(rows + (size_t)min(r, nrows - 1) * 8); };
     uint2 n1 = row_at(n), n2 = row_at(16 + n);
+    int walked = 0;
     for (int tb = 0; tb < nrows; tb += 16) {
         const uint32_t w[2] = {n1.x, n1.y};
         n1 = n2;
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __rest
             const v4i& d = acc[qt];
             const int m = min(min(d[0], d[1]), min(d[2], d[3]));
             if (__any(m <= thr[qt]) || tail) {
+                ++walked;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t r = rowbase + (uint32_t)j;
@@ -154,6 +161,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_best2_mfma(const uint32_t* __rest
         const int qi = (int)blockIdx.y * kMfmaQueries + qt * 16 + n;
         if (grp == 0 && qi < nq) { Part p; p.best = b; p.second = s2; parts[(size_t)chunk * nq + qi] = p; }
     }
+    if (lane == 0) atomicAdd(&g_best2_walked, (unsigned long long)walked);
 }
 
 // one thread per query: fold the per-chunk partial results in chunk (= index) order
@@ -848,6 +856,16 @@ constexpr size_t kStaticPartBytes = 4u << 20;
 constexpr size_t kStaticSeedBytes = sizeof(orbx_best2) * kStaticMaxQueries;
 static __device__ __align__(256) unsigned char scratch[kStaticPartBytes + kStaticSeedBytes];
 
+// Calls of the static entry point on one GPU share that GPU's scratch whatever matcher or stream they come from, so they
+// are put in order: one event per device (created with the first matcher of that device, never destroyed), waited for in
+// front of a call's launches and recorded behind them, under a host lock so that two host threads cannot interleave the
+// wait / launch / record of their calls.  Neither allocates.  A call under stream capture skips both (an event wait would
+// become part of the caller's graph): captured calls stay the caller's to order.
+constexpr int kMaxStaticDevices = 64;
+static hipEvent_t g_static_done[kMaxStaticDevices] = {};
+static std::mutex g_static_mu[kMaxStaticDevices];
+static std::mutex g_static_create_mu;
+
 struct orbx_matcher {
     int device = 0;
     void* static_scratch = nullptr;                // this device's address of `scratch`, resolved at create
@@ -901,6 +919,10 @@ int orbx_matcher_create(int device, orbx_matcher** out)
     HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     // the matcher's device is current here: this is that device's copy of the array
     HIP_CHECK(hipGetSymbolAddress(&m->static_scratch, HIP_SYMBOL(scratch)));
+    if (m->device < kMaxStaticDevices) {
+        std::lock_guard<std::mutex> lock(g_static_create_mu);
+        if (!g_static_done[m->device]) HIP_CHECK(hipEventCreateWithFlags(&g_static_done[m->device], hipEventDisableTiming));
+    }
     guard.p = nullptr;
     *out = m;
     return ORBX_OK;
@@ -998,8 +1020,31 @@ int orbx_hamming_best2_device_static(orbx_matcher* m, const uint8_t* d_q, int nq
     }
     HIP_CHECK(hipSetDevice(m->device));
     unsigned char* base = static_cast<unsigned char*>(m->static_scratch);
-    return launch_best2(d_q, nq, d_t, nt, index_base, d_out, (hipStream_t)stream, reinterpret_cast<Part*>(base),
-                        reinterpret_cast<orbx_best2*>(base + kStaticPartBytes), seeded, rpc, nch, rpc1, nch1);
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    HIP_CHECK(hipStreamIsCapturing(st, &capturing));
+    const bool ordered = capturing == hipStreamCaptureStatusNone && m->device < kMaxStaticDevices && g_static_done[m->device];
+    if (!ordered)
+        return launch_best2(d_q, nq, d_t, nt, index_base, d_out, st, reinterpret_cast<Part*>(base),
+                            reinterpret_cast<orbx_best2*>(base + kStaticPartBytes), seeded, rpc, nch, rpc1, nch1);
+    std::lock_guard<std::mutex> lock(g_static_mu[m->device]);
+    HIP_CHECK(hipStreamWaitEvent(st, g_static_done[m->device], 0));      // behind the last call that used this GPU's scratch
+    rc = launch_best2(d_q, nq, d_t, nt, index_base, d_out, st, reinterpret_cast<Part*>(base),
+                      reinterpret_cast<orbx_best2*>(base + kStaticPartBytes), seeded, rpc, nch, rpc1, nch1);
+    HIP_CHECK(hipEventRecord(g_static_done[m->device], st));
+    return rc;
+}
+
+int orbx_debug_best2_tile_walks(orbx_matcher* m, uint64_t* walked, int reset)
+{
+    if (!m || !walked) { set_error("orbx_debug_best2_tile_walks: null pointer"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(m->device));
+    HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    HIP_CHECK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_best2_walked), sizeof(v)));
+    *walked = v;
+    if (reset) { v = 0; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_best2_walked), &v, sizeof(v))); }
+    return ORBX_OK;
 }
 
 int orbx_best2_merge_device(orbx_matcher* m, const orbx_best2* d_parts, int n_parts, int nq, orbx_best2* d_out, void* stream)
