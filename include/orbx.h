@@ -253,8 +253,12 @@ int orbx_search_for_initialization(orbx_matcher* m,
  * histogram and the vbPrevMatched update of :518-520 all happen there).  Keypoint, descriptor and count arrays are laid
  * out like the outputs of orbx_extract_batch_device (pair p at offset p * cap); pass a batch's own outputs, or its
  * undistorted copy, directly.  d_prev_matched_xy[n_pairs][cap][2] in / out, d_matches12[n_pairs][cap] (-1 past each
- * count), d_nmatches[n_pairs].  ORBX_ERR_CAPACITY when cap is above 2690 (the pair's octave-0 features live in LDS).
- * Runs on `stream`; nothing is allocated. */
+ * count), d_nmatches[n_pairs].  While 53 bytes per keypoint of cap fit 150 KB of LDS (cap up to about 2890) everything a
+ * pair needs lives there and nothing is allocated; above that -- the reference's initialisation extractor runs at
+ * 2 * nFeatures, src/Tracking.cc:136-137 -- frame 2's descriptors and positions go to a device-memory arena of the matcher
+ * (44 bytes per keypoint and pair, grown with hipMalloc when a call needs more than the last: calls on one matcher must
+ * not overlap) and LDS keeps the 9 bytes per keypoint of the sequential pass.  ORBX_ERR_CAPACITY above about 17000.
+ * Runs on `stream`. */
 int orbx_search_for_initialization_batch_device(orbx_matcher* m,
                                                 const orbx_keypoint* d_k1, const uint8_t* d_d1, const int32_t* d_n1,
                                                 const orbx_keypoint* d_k2, const uint8_t* d_d2, const int32_t* d_n2, int cap, int n_pairs,
@@ -295,8 +299,11 @@ int orbx_search_by_projection_lastframe(orbx_matcher* m,
  * (mode, th_dist, check_ori as above); form 1: the map-point search (nnratio).  Call c reads its queries at c * qcap
  * (d_nq[c] of them; d_qur may be null when d_uright2 is, d_qangle when check_ori is 0, d_q_transient always) and its
  * frame at c * cap (d_n2[c] features; d_uright2 may be null), and updates d_claimed[c * cap ..] in place as the host
- * forms do; d_nmatches[c] receives the count.  ORBX_ERR_CAPACITY when 57 * cap + 3 * qcap bytes exceed ~135 KB of LDS
- * (cap about 2400).  Runs on `stream`; nothing is allocated. */
+ * forms do; d_nmatches[c] receives the count.  While 57 * cap + 3 * qcap + 12 KB fit 150 KB of LDS (cap about 2400 at
+ * qcap 1000) nothing is allocated; above that the frame's descriptors and per-feature constants go to a device-memory
+ * arena of the matcher (53 bytes per feature and call, grown with hipMalloc when needed: calls on one matcher must not
+ * overlap) and LDS keeps the claim states and the cell table (4 * cap + 3 * qcap + 12 KB): ORBX_ERR_CAPACITY only when
+ * that exceeds 150 KB (cap about 30000 at qcap 4000) or cap reaches 65536.  Runs on `stream`. */
 int orbx_search_by_projection_batch_device(orbx_matcher* m, int form,
                                            const float* d_qu, const float* d_qv, const float* d_qradius, const float* d_qur,
                                            const int32_t* d_qlevel, const float* d_qangle, const uint8_t* d_qdesc, const uint8_t* d_q_transient,

@@ -417,11 +417,17 @@ __global__ __launch_bounds__(1024) void k_window_scan(int32_t* __restrict__ rowp
 // grid row, keypoint index (src/Frame.cc:350-376: strict `<` lets the first visited of equal distances win); the second
 // best distance is the second smallest of the multiset, which is what the sequential update of :449-459 yields.
 // Rotation histogram, ComputeThreeMaxima, the removal of the other bins and the update of vbPrevMatched follow.
-// LDS per pair: 57 bytes per keypoint of capacity (kInitLdsPerKeypoint).
+// Per keypoint of capacity: 44 bytes that are written once (descriptor, position, visiting-order key: the frame part) and
+// 9 bytes of state of the sequential pass.  Both live in LDS while they fit (kFrameInGlobal false); for larger
+// capacities -- the reference's initialisation extractor runs at twice nFeatures, src/Tracking.cc:136-137 -- the frame
+// part moves to a per-pair slice of a device-memory arena (served by the CU's L1 / L2) and LDS keeps the state only.
 // ---------------------------------------------------------------------------------------------
 constexpr int kHistoLength = 30;
 constexpr int kThLow = 50;
-constexpr int kInitLdsPerKeypoint = 57;
+constexpr int kInitFramePerKeypoint = 44, kInitStatePerKeypoint = 9;
+constexpr size_t kMatchLdsLimit = 150 * 1024;
+static size_t init_frame_bytes(int cap) { return ((size_t)cap * kInitFramePerKeypoint + 15) & ~(size_t)15; }
+static size_t init_state_bytes(int cap) { return (size_t)cap * kInitStatePerKeypoint + 16; }
 
 __device__ __forceinline__ int rotation_bin_dev(float a1, float a2)      // :476-482 (factor = 1/HISTO_LENGTH: bins 0..12 only)
 {
@@ -470,26 +476,33 @@ __device__ __forceinline__ int wave_min_i32(int v)          // values >= 0 only
     return (int)wave_min_u32((uint32_t)v);
 }
 
+template <bool kFrameInGlobal>
 __global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restrict__ k1, const uint32_t* __restrict__ d1, const int32_t* __restrict__ n1v,
                                                    const orbx_keypoint* __restrict__ k2, const uint32_t* __restrict__ d2, const int32_t* __restrict__ n2v,
                                                    int cap, float minX, float minY, float invW, float invH,
                                                    float* __restrict__ prev_xy, float window, float nnratio, int check_ori,
-                                                   int32_t* __restrict__ matches12, int32_t* __restrict__ nmatches)
+                                                   int32_t* __restrict__ matches12, int32_t* __restrict__ nmatches,
+                                                   unsigned char* __restrict__ arena, unsigned long long arena_stride)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    // frame 2, octave 0, in keypoint order: descriptor, position, visiting-order key, state of the sequential pass
-    uint4* s_desc = reinterpret_cast<uint4*>(smem);                                  // 2 x uint4 per entry
-    float2* s_xy = reinterpret_cast<float2*>(smem + (size_t)cap * 32);
-    uint32_t* s_okey = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 40);         // cellx << 26 | celly << 20 | index
-    int32_t* s_m21 = reinterpret_cast<int32_t*>(smem + (size_t)cap * 44);            // vnMatches21
-    uint16_t* s_mdist = reinterpret_cast<uint16_t*>(smem + (size_t)cap * 48);        // vMatchedDistance (0xFFFF = INT_MAX)
-    uint16_t* s_qlist = reinterpret_cast<uint16_t*>(smem + (size_t)cap * 50);        // octave-0 keypoints of frame 1
-    int32_t* s_m12 = reinterpret_cast<int32_t*>(smem + (size_t)cap * 52);            // vnMatches12
-    uint8_t* s_bin = smem + (size_t)cap * 56;                                        // histogram bin a query was pushed to (255: none)
-    __shared__ int s_hist[kHistoLength];
-
     const int lane = threadIdx.x;
     const int pair = blockIdx.x;
+    // frame 2, octave 0, in keypoint order: descriptor, position, visiting-order key (written once) ...
+    const size_t frame_bytes = ((size_t)cap * kInitFramePerKeypoint + 15) & ~(size_t)15;
+    unsigned char* fbase = kFrameInGlobal ? arena + (size_t)pair * arena_stride : smem;
+    uint4* s_desc = reinterpret_cast<uint4*>(fbase);                                 // 2 x uint4 per entry
+    float2* s_xy = reinterpret_cast<float2*>(fbase + (size_t)cap * 32);
+    uint32_t* s_okey = reinterpret_cast<uint32_t*>(fbase + (size_t)cap * 40);        // cellx << 26 | celly << 20 | index
+    // ... and the state of the sequential pass (always LDS); indices as 16 bits (the capacity is below 65535), 0xFFFF = none
+    unsigned char* mbase = kFrameInGlobal ? smem : smem + frame_bytes;
+    uint16_t* s_m21 = reinterpret_cast<uint16_t*>(mbase);                            // vnMatches21
+    uint16_t* s_mdist = reinterpret_cast<uint16_t*>(mbase + (size_t)cap * 2);        // vMatchedDistance (0xFFFF = INT_MAX)
+    uint16_t* s_qlist = reinterpret_cast<uint16_t*>(mbase + (size_t)cap * 4);        // octave-0 keypoints of frame 1
+    uint16_t* s_m12 = reinterpret_cast<uint16_t*>(mbase + (size_t)cap * 6);          // vnMatches12
+    uint8_t* s_bin = mbase + (size_t)cap * 8;                                        // histogram bin a query was pushed to (255: none)
+    __shared__ int s_hist[kHistoLength];
+    constexpr uint16_t kNone = 0xFFFFu;
+
     const size_t off = (size_t)pair * cap;
     k1 += off; k2 += off; d1 += off * 8; d2 += off * 8; prev_xy += off * 2; matches12 += off;
     const int n1 = min(n1v[pair], cap), n2 = min(n2v[pair], cap);
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restri
             s_desc[2 * pos] = tp[0]; s_desc[2 * pos + 1] = tp[1];
             s_xy[pos] = make_float2(x, y);
             s_okey[pos] = ((uint32_t)px << 26) | ((uint32_t)py << 20) | (uint32_t)j;
-            s_m21[pos] = -1; s_mdist[pos] = 0xFFFFu;
+            s_m21[pos] = kNone; s_mdist[pos] = 0xFFFFu;
         }
         n0 += __popcll(m);
     }
@@ -524,7 +537,7 @@ __global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restri
         const unsigned long long m = __ballot(on);
         if (on) s_qlist[nq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
         nq += __popcll(m);
-        if (i < n1) { s_m12[i] = -1; s_bin[i] = 255; }
+        if (i < n1) { s_m12[i] = kNone; s_bin[i] = 255; }
     }
     if (lane < kHistoLength) s_hist[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -574,9 +587,9 @@ __global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restri
             const int wj = __builtin_amdgcn_readlane(bestj, __ffsll((long long)__ballot(winner)) - 1);
             const int i2 = (int)(s_okey[wj] & 0xFFFFFu);
             if (lane == 0) {
-                const int prev = s_m21[wj];
-                if (prev >= 0) s_m12[prev] = -1;                           // :466-470
-                s_m12[i1] = i2; s_m21[wj] = i1; s_mdist[wj] = (uint16_t)bestDist;
+                const uint16_t prev = s_m21[wj];
+                if (prev != kNone) s_m12[prev] = kNone;                    // :466-470
+                s_m12[i1] = (uint16_t)i2; s_m21[wj] = (uint16_t)i1; s_mdist[wj] = (uint16_t)bestDist;
                 if (check_ori) { const int bin = rotation_bin_dev(k1[i1].angle, k2[i2].angle); s_bin[i1] = (uint8_t)bin; ++s_hist[bin]; }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -599,7 +612,7 @@ __global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restri
         const int i = i0 + lane;
         int mt = -1;
         if (i < n1) {
-            mt = s_m12[i];
+            mt = s_m12[i] == kNone ? -1 : (int)s_m12[i];
             const int bin = s_bin[i];
             if (check_ori && bin != 255 && bin != ind1 && bin != ind2 && bin != ind3) mt = -1;
             matches12[i] = mt;
@@ -627,7 +640,13 @@ __global__ __launch_bounds__(64) void k_init_match(const orbx_keypoint* __restri
 // ---------------------------------------------------------------------------------------------
 constexpr int kThHigh = 100;
 
-template <int FORM>
+constexpr int kProjFramePerKeypoint = 53;         // descriptor 32, position 8, visiting-order key 4, angle 4, right coordinate 4, octave 1
+static size_t proj_frame_bytes(int cap) { return ((size_t)cap * kProjFramePerKeypoint + 15) & ~(size_t)15; }
+static size_t proj_state_bytes(int cap, int qcap) { return (((size_t)cap * 4 + 15) & ~(size_t)15) + 3080 * 4 + (size_t)qcap * 3 + 16; }
+
+// kFrameInGlobal: the per-feature data that is written once (53 bytes per feature) lives in a per-call slice of a
+// device-memory arena instead of LDS, which then holds the claim states, the cell table and the accepted-match list only
+template <int FORM, bool kFrameInGlobal>
 __global__ __launch_bounds__(64) void k_proj_match(const float* __restrict__ qu, const float* __restrict__ qv, const float* __restrict__ qradius,
                                                    const float* __restrict__ qur, const int32_t* __restrict__ qlevel, const float* __restrict__ qangle,
                                                    const uint32_t* __restrict__ qdesc, const uint8_t* __restrict__ qtransient,
@@ -635,17 +654,21 @@ __global__ __launch_bounds__(64) void k_proj_match(const float* __restrict__ qu,
                                                    const orbx_keypoint* __restrict__ k2, const uint32_t* __restrict__ d2, const float* __restrict__ uright2,
                                                    const int32_t* __restrict__ n2v, int cap,
                                                    float minX, float minY, float invW, float invH, int mode, int th_dist, float nnratio, int check_ori,
-                                                   int32_t* __restrict__ claimed, int32_t* __restrict__ nmatches)
+                                                   int32_t* __restrict__ claimed, int32_t* __restrict__ nmatches,
+                                                   unsigned char* __restrict__ arena, unsigned long long arena_stride)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint4* s_desc = reinterpret_cast<uint4*>(smem);                                  // 2 x uint4 per entry
-    float2* s_xy = reinterpret_cast<float2*>(smem + (size_t)cap * 32);
-    uint32_t* s_okey = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 40);         // column << 26 | row << 20 | index
-    float* s_angle = reinterpret_cast<float*>(smem + (size_t)cap * 44);
-    float* s_ur = reinterpret_cast<float*>(smem + (size_t)cap * 48);
-    int32_t* s_claim = reinterpret_cast<int32_t*>(smem + (size_t)cap * 52);
-    uint8_t* s_oct = smem + (size_t)cap * 56;
-    const size_t o_cells = ((size_t)cap * 57 + 15) & ~(size_t)15;
+    const size_t frame_bytes = ((size_t)cap * kProjFramePerKeypoint + 15) & ~(size_t)15;
+    unsigned char* fbase = kFrameInGlobal ? arena + (size_t)blockIdx.x * arena_stride : smem;
+    uint4* s_desc = reinterpret_cast<uint4*>(fbase);                                 // 2 x uint4 per entry
+    float2* s_xy = reinterpret_cast<float2*>(fbase + (size_t)cap * 32);
+    uint32_t* s_okey = reinterpret_cast<uint32_t*>(fbase + (size_t)cap * 40);        // column << 26 | row << 20 | index
+    float* s_angle = reinterpret_cast<float*>(fbase + (size_t)cap * 44);
+    float* s_ur = reinterpret_cast<float*>(fbase + (size_t)cap * 48);
+    uint8_t* s_oct = fbase + (size_t)cap * 52;
+    unsigned char* mbase = kFrameInGlobal ? smem : smem + frame_bytes;
+    int32_t* s_claim = reinterpret_cast<int32_t*>(mbase);
+    const size_t o_cells = (size_t)(mbase - smem) + (((size_t)cap * 4 + 15) & ~(size_t)15);
     int32_t* s_cell = reinterpret_cast<int32_t*>(smem + o_cells);                    // [3073] first entry of every cell, column-major
     uint16_t* s_hj = reinterpret_cast<uint16_t*>(smem + o_cells + 3080 * 4);         // accepted matches: entry ...
     uint8_t* s_hb = smem + o_cells + 3080 * 4 + (size_t)qcap * 2;                    // ... and histogram bin
@@ -874,6 +897,7 @@ struct orbx_matcher {
     void* seed = nullptr; size_t seed_bytes = 0;   // its per-query result over the first rows (threshold seed of the full pass)
     void* stage[8] = {}; size_t stage_bytes[8] = {}; // staging buffers of the host entry points
     void* win = nullptr; size_t win_bytes = 0;       // device arena of the windowed candidate generation
+    void* arena = nullptr; size_t arena_bytes = 0;   // frame part of the batched device matchers when it does not fit LDS (grows; calls on one matcher must not overlap)
     uint8_t* pin = nullptr; size_t pin_bytes = 0;    // pinned host mirror of it (one upload, two small downloads per call)
 };
 
@@ -937,6 +961,7 @@ void orbx_matcher_destroy(orbx_matcher* m)
     if (m->seed) (void)hipFree(m->seed);
     for (void* p : m->stage) if (p) (void)hipFree(p);
     if (m->win) (void)hipFree(m->win);
+    if (m->arena) (void)hipFree(m->arena);
     if (m->pin) (void)hipHostFree(m->pin);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -1111,14 +1136,30 @@ int orbx_search_for_initialization_batch_device(orbx_matcher* m, const orbx_keyp
     if (!m || cap < 1 || n_pairs < 0 || !(maxX > minX) || !(maxY > minY)) { set_error("orbx_search_for_initialization_batch_device: bad argument"); return ORBX_ERR_BAD_ARG; }
     if (n_pairs == 0) return ORBX_OK;
     if (!d_k1 || !d_d1 || !d_n1 || !d_k2 || !d_d2 || !d_n2 || !d_prev_matched_xy || !d_matches12 || !d_nmatches) { set_error("orbx_search_for_initialization_batch_device: null pointer"); return ORBX_ERR_BAD_ARG; }
-    const size_t lds = (size_t)cap * kInitLdsPerKeypoint + 16;
-    if (lds > 150 * 1024 || cap >= (1 << 16)) { set_error("orbx_search_for_initialization_batch_device: per-frame capacity above 2690 keypoints does not fit the LDS of one CU"); return ORBX_ERR_CAPACITY; }
+    if (cap >= 65535) { set_error("orbx_search_for_initialization_batch_device: per-frame capacity must be below 65535 (16-bit match indices)"); return ORBX_ERR_CAPACITY; }
     HIP_CHECK(hipSetDevice(m->device));
-    HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_init_match), lds));
     const float invW = 64.0f / (maxX - minX), invH = 48.0f / (maxY - minY);      // Frame::mfGridElementWidthInv / HeightInv, src/Frame.cc:101-102
-    hipLaunchKernelGGL(k_init_match, dim3(n_pairs), dim3(64), lds, (hipStream_t)stream, d_k1, reinterpret_cast<const uint32_t*>(d_d1), d_n1,
-                       d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_n2, cap, minX, minY, invW, invH, d_prev_matched_xy, (float)window, nnratio,
-                       check_ori, d_matches12, d_nmatches);
+    const size_t lds_all = init_frame_bytes(cap) + init_state_bytes(cap);
+    if (lds_all <= kMatchLdsLimit) {
+        HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_init_match<false>), lds_all));
+        hipLaunchKernelGGL(k_init_match<false>, dim3(n_pairs), dim3(64), lds_all, (hipStream_t)stream, d_k1, reinterpret_cast<const uint32_t*>(d_d1), d_n1,
+                           d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_n2, cap, minX, minY, invW, invH, d_prev_matched_xy, (float)window, nnratio,
+                           check_ori, d_matches12, d_nmatches, (unsigned char*)nullptr, 0ull);
+    } else {
+        // frame part in a device-memory arena of the matcher (one slice per pair), state in LDS
+        const size_t lds = init_state_bytes(cap);
+        if (lds > kMatchLdsLimit) {
+            set_error("orbx_search_for_initialization_batch_device: per-frame capacity above 17000 keypoints: the state of the sequential pass (9 bytes per keypoint) does not fit the LDS of one CU");
+            return ORBX_ERR_CAPACITY;
+        }
+        const size_t stride = init_frame_bytes(cap);
+        int rc;
+        if ((rc = reserve(&m->arena, &m->arena_bytes, stride * (size_t)n_pairs))) return rc;
+        HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_init_match<true>), lds));
+        hipLaunchKernelGGL(k_init_match<true>, dim3(n_pairs), dim3(64), lds, (hipStream_t)stream, d_k1, reinterpret_cast<const uint32_t*>(d_d1), d_n1,
+                           d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_n2, cap, minX, minY, invW, invH, d_prev_matched_xy, (float)window, nnratio,
+                           check_ori, d_matches12, d_nmatches, (unsigned char*)m->arena, (unsigned long long)stride);
+    }
     HIP_CHECK(hipGetLastError());
     return ORBX_OK;
 }
@@ -1139,22 +1180,34 @@ int orbx_search_by_projection_batch_device(orbx_matcher* m, int form,
         (d_uright2 && !d_qur) || (form == 0 && check_ori && !d_qangle)) {
         set_error("orbx_search_by_projection_batch_device: null pointer"); return ORBX_ERR_BAD_ARG;
     }
-    const size_t lds = (((size_t)cap * 57 + 15) & ~(size_t)15) + 3080 * 4 + (size_t)qcap * 3 + 16;
-    if (lds > 150 * 1024 || cap >= (1 << 16) || qcap >= (1 << 20)) {
-        set_error("orbx_search_by_projection_batch_device: frame capacity (57 bytes per feature) plus 3 bytes per query do not fit the LDS of one CU"); return ORBX_ERR_CAPACITY;
-    }
+    if (cap >= (1 << 16) || qcap >= (1 << 20)) { set_error("orbx_search_by_projection_batch_device: capacities must stay below 65536 features / 1048576 queries"); return ORBX_ERR_CAPACITY; }
     HIP_CHECK(hipSetDevice(m->device));
     const float invW = 64.0f / (maxX - minX), invH = 48.0f / (maxY - minY);      // src/Frame.cc:101-102
-    const void* fn = form == 0 ? reinterpret_cast<const void*>(k_proj_match<0>) : reinterpret_cast<const void*>(k_proj_match<1>);
-    HIP_CHECK((hipError_t)raise_dynamic_lds(fn, lds));
-    if (form == 0)
-        hipLaunchKernelGGL(k_proj_match<0>, dim3(n_calls), dim3(64), lds, (hipStream_t)stream, d_qu, d_qv, d_qradius, d_qur, d_qlevel, d_qangle,
-                           reinterpret_cast<const uint32_t*>(d_qdesc), d_q_transient, d_nq, qcap, d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_uright2,
-                           d_n2, cap, minX, minY, invW, invH, mode, th_dist, nnratio, check_ori, d_claimed, d_nmatches);
-    else
-        hipLaunchKernelGGL(k_proj_match<1>, dim3(n_calls), dim3(64), lds, (hipStream_t)stream, d_qu, d_qv, d_qradius, d_qur, d_qlevel, d_qangle,
-                           reinterpret_cast<const uint32_t*>(d_qdesc), d_q_transient, d_nq, qcap, d_k2, reinterpret_cast<const uint32_t*>(d_d2), d_uright2,
-                           d_n2, cap, minX, minY, invW, invH, mode, th_dist, nnratio, check_ori, d_claimed, d_nmatches);
+    const size_t lds_all = proj_frame_bytes(cap) + proj_state_bytes(cap, qcap);
+    const bool in_lds = lds_all <= kMatchLdsLimit;
+    const size_t lds = in_lds ? lds_all : proj_state_bytes(cap, qcap);
+    if (lds > kMatchLdsLimit) {
+        set_error("orbx_search_by_projection_batch_device: 4 bytes per feature plus 3 bytes per query of capacity (claim states and accepted matches) do not fit the LDS of one CU");
+        return ORBX_ERR_CAPACITY;
+    }
+    unsigned char* arena = nullptr;
+    const size_t stride = proj_frame_bytes(cap);
+    if (!in_lds) {
+        int rc;
+        if ((rc = reserve(&m->arena, &m->arena_bytes, stride * (size_t)n_calls))) return rc;
+        arena = (unsigned char*)m->arena;
+    }
+#define ORBX_LAUNCH_PROJ(FORM, G)                                                                                                              \
+    do {                                                                                                                                       \
+        HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_proj_match<FORM, G>), lds));                                   \
+        hipLaunchKernelGGL((k_proj_match<FORM, G>), dim3(n_calls), dim3(64), lds, (hipStream_t)stream, d_qu, d_qv, d_qradius, d_qur, d_qlevel, \
+                           d_qangle, reinterpret_cast<const uint32_t*>(d_qdesc), d_q_transient, d_nq, qcap, d_k2,                              \
+                           reinterpret_cast<const uint32_t*>(d_d2), d_uright2, d_n2, cap, minX, minY, invW, invH, mode, th_dist, nnratio,      \
+                           check_ori, d_claimed, d_nmatches, arena, (unsigned long long)stride);                                               \
+    } while (0)
+    if (form == 0) { if (in_lds) ORBX_LAUNCH_PROJ(0, false); else ORBX_LAUNCH_PROJ(0, true); }
+    else { if (in_lds) ORBX_LAUNCH_PROJ(1, false); else ORBX_LAUNCH_PROJ(1, true); }
+#undef ORBX_LAUNCH_PROJ
     HIP_CHECK(hipGetLastError());
     return ORBX_OK;
 }
