@@ -556,6 +556,27 @@ def worker(a):
     csteps = max(2, a.steps // 4)
     t_copy = cx.timed(job.step, csteps, min(a.warmup, 3))
     fps_copy = n_gpus * B * csteps / t_copy
+    # one caller stream, one call per step: orbx_extract_batch_device_multi spreads the batch over the same contexts and
+    # joins them on the caller's stream (frames in the input views, as in the headline)
+    one_stream = torch.cuda.current_stream().cuda_stream
+
+    def one_call_step():
+        vsa.extract_batch_device_multi(job.exs, None, 0, 0, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, one_stream)
+
+    def one_call_nojoin_step():
+        vsa.extract_batch_device_multi(job.exs, None, 0, 0, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, one_stream, join=False)
+
+    fps_one_call = fps_one_call_nojoin = None
+    if C > 1 and job.per == job.chunk:
+        t_one = cx.timed(one_call_step, csteps, min(a.warmup, 3))
+        fps_one_call = n_gpus * B * csteps / t_one
+        t_one = cx.timed(one_call_nojoin_step, csteps, min(a.warmup, 3))     # the barrier's device synchronise is the join
+        fps_one_call_nojoin = n_gpus * B * csteps / t_one
+    # ... and a single context on a single stream working through the same batch in launches of the same size
+    solo = ExtractJob(cx, vsa, np, p, W, H, job.chunk, 1, job.chunk, seed0=rank * 100000, stereo_right=None)
+    t_solo = cx.timed(solo.step, csteps * 2, min(a.warmup, 3))
+    fps_solo = n_gpus * job.chunk * csteps * 2 / t_solo
+    solo.close()
     job.close()
 
     # per-stage device time: HIP events recorded by the library on the launch stream around each stage, one launch of
@@ -650,6 +671,9 @@ def worker(a):
                        "input": "frames resident in the extractors' input views (orbx_extractor_input_view: level 0 of the pyramid, "
                                 "no copy at the start of a launch); copy_input_value is the same step from a plain width-strided buffer",
                        "copy_input_value": fps_copy,
+                       "one_call_value": fps_one_call,      # the same contexts behind one call on one caller stream (orbx_extract_batch_device_multi)
+                       "one_call_no_join_value": fps_one_call_nojoin,   # ... with ORBX_MULTI_NO_JOIN: calls queued back to back, joined once at the end
+                       "one_context_value": fps_solo,       # contexts_per_gpu = 1: one extractor, one stream
                        "frames_per_gpu_per_step": B, "contexts_per_gpu": C, "frames_per_launch": PB, "mean_keypoints_per_frame": round(mean_kp, 1),
                        "parallelism": f"frames sharded over {n_gpus} GPU(s), no collective"},
             "ranks_seen": seen, "build_stamp": vsa.build_stamp(),

@@ -113,6 +113,25 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
                               ptrdiff_t frame_stride, int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc,
                               int32_t* d_counts, int cap_per_frame, void* stream);
 
+/* One call, several contexts (no counterpart in the reference, whose callers run one extractor per thread and two for
+ * stereo, src/Frame.cc:78-81): the batch is cut into n_contexts contiguous shares, context c extracts share c on its own
+ * internal stream, and `stream` is joined behind all of them, so a caller with one stream gets the overlap of several
+ * contexts without managing streams (kernels of different contexts fill each other's gaps; four contexts is what a
+ * process's four hardware queues run side by side).  The contexts must have been created with equal parameters, image
+ * size, input format and device, each with max_batch >= ceil(n_frames / n_contexts).  Work queued on `stream` before the
+ * call (the producer of the frames) is waited for by every context.  d_images == NULL: context c reads the frames of its
+ * share from its own input view (orbx_extractor_input_view), where the caller has put them.  Outputs as for
+ * orbx_extract_batch_device, frame f of the batch at f * cap_per_frame.  Not under stream capture.
+ * flags: ORBX_MULTI_NO_JOIN leaves `stream` unjoined, for callers that queue several batches back to back (other
+ * output buffers, or results not needed in between): the contexts then run on without meeting at the end of every call,
+ * which is worth about 8 % at 1024 frames per call; orbx_extract_multi_join(exs, n_contexts, stream) makes `stream` wait
+ * for everything the contexts have been given so far. */
+enum { ORBX_MULTI_NO_JOIN = 1 };
+int orbx_extract_batch_device_multi(orbx_extractor* const* exs, int n_contexts, const uint8_t* d_images, ptrdiff_t row_stride,
+                                    ptrdiff_t frame_stride, int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc,
+                                    int32_t* d_counts, int cap_per_frame, void* stream, int flags);
+int orbx_extract_multi_join(orbx_extractor* const* exs, int n_contexts, void* stream);
+
 /* Zero-copy input (no counterpart in the reference, whose ComputePyramid copies the image into its padded level 0,
  * src/ORBextractor.cc:1124-1128): where level 0 of the context's pyramid lives.  A producer that can write its
  * grey frames there -- frame f, row y, column x at d_images[f * frame_stride + y * row_stride + x], f < max_batch --

@@ -561,3 +561,46 @@ def test_geometry_beyond_the_launch_grid_is_refused_at_create(vsa):
     with pytest.raises(vsa.OrbxError) as e:
         vsa.Extractor(vsa.make_params(20000, 1.1, 16, 20, 7), 4096, 4096, max_batch=1, device=0)
     assert e.value.status == 2 and "workgroups per frame" in str(e.value), str(e.value)
+
+
+def test_one_call_over_several_contexts(vsa):
+    """orbx_extract_batch_device_multi: one call, four contexts on their own streams, joined on the caller's stream --
+    the outputs equal those of one context working through the whole batch, from a plain buffer and from the input views."""
+    import torch
+    w, h, B, C = 640, 480, 10, 4                       # shares of 3, 3, 3, 1
+    p = vsa.make_params(1000, 1.2, 8, 20, 7)
+    imgs = np.stack([vsa.synth_frame(60 + i, w, h) for i in range(B)])
+    d = torch.from_numpy(imgs).cuda()
+    one = vsa.Extractor(p, w, h, max_batch=B, device=0)
+    cap = one.cap
+    def outputs():
+        return (torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"), torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                torch.zeros(B, dtype=torch.int32, device="cuda"))
+    st = torch.cuda.current_stream().cuda_stream
+    k0, d0, c0 = outputs()
+    one.extract_batch_device(d.data_ptr(), w, w * h, B, k0.data_ptr(), d0.data_ptr(), c0.data_ptr(), cap, st)
+    torch.cuda.synchronize()
+    exs = [vsa.Extractor(p, w, h, max_batch=3, device=0) for _ in range(C)]
+    k1, d1, c1 = outputs()
+    vsa.extract_batch_device_multi(exs, d.data_ptr(), w, w * h, B, k1.data_ptr(), d1.data_ptr(), c1.data_ptr(), cap, st)
+    got_counts = c1.cpu().numpy()                      # a read on the caller's stream: the join makes it safe without a device synchronise
+    assert np.array_equal(got_counts, c0.cpu().numpy()) and got_counts.min() > 500
+    assert torch.equal(k0.view(torch.int32), k1.view(torch.int32)) and torch.equal(d0, d1)
+    # the same through the input views: context c holds frames 3c .. 3c+2 of the batch
+    for c, ex in enumerate(exs):
+        n = min(3, B - 3 * c)
+        torch.as_tensor(ex.input_view_array(n), device="cuda").copy_(d[3 * c:3 * c + n])
+    k2, d2, c2 = outputs()
+    vsa.extract_batch_device_multi(exs, None, 0, 0, B, k2.data_ptr(), d2.data_ptr(), c2.data_ptr(), cap, st)
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c2) and torch.equal(k0.view(torch.int32), k2.view(torch.int32)) and torch.equal(d0, d2)
+    with pytest.raises(vsa.OrbxError):                 # a share larger than a context's max_batch
+        vsa.extract_batch_device_multi(exs[:2], d.data_ptr(), w, w * h, B, k2.data_ptr(), d2.data_ptr(), c2.data_ptr(), cap, st)
+    # deferred join: two calls back to back, one join
+    k3, d3, c3 = outputs()
+    vsa.extract_batch_device_multi(exs, d.data_ptr(), w, w * h, B, k3.data_ptr(), d3.data_ptr(), c3.data_ptr(), cap, st, join=False)
+    vsa.extract_batch_device_multi(exs, d.data_ptr(), w, w * h, B, k3.data_ptr(), d3.data_ptr(), c3.data_ptr(), cap, st, join=False)
+    vsa.extract_multi_join(exs, st)
+    assert torch.equal(c0.cpu(), c3.cpu()) and torch.equal(k0.view(torch.int32), k3.view(torch.int32)) and torch.equal(d0, d3)
+    for e in exs + [one]:
+        e.close()

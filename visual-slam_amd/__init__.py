@@ -70,6 +70,8 @@ _SIGS = {
     "orbx_extract": (_i, [_vp, _vp, _pd, _vp, _vp, _i, C.POINTER(_i)]),
     "orbx_extract_batch": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i, _vp]),
+    "orbx_extract_batch_device_multi": (_i, [_vp, _i, _vp, _pd, _pd, _i, _vp, _vp, _vp, _i, _vp, _i]),
+    "orbx_extract_multi_join": (_i, [_vp, _i, _vp]),
     "orbx_extractor_input_view": (_i, [_vp, C.POINTER(_vp), C.POINTER(_pd), C.POINTER(_pd)]),
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _pd]),
     "orbx_pyramid_levels": (_i, [_vp, _i, _vp, _vp]),
@@ -384,6 +386,18 @@ class Extractor:
         ms = np.zeros(len(STAGES), np.float32)
         _check(lib.orbx_extractor_stage_ms(self.h, _ptr(ms)))
         return ms
+
+
+def extract_batch_device_multi(extractors, d_images, row_stride, frame_stride, n_frames, d_kps, d_desc, d_counts, cap, stream=None, join=True):
+    """One call over several contexts (orbx_extract_batch_device_multi); d_images None: every context reads its input view."""
+    arr = (_vp * len(extractors))(*[e.h for e in extractors])
+    _check(lib.orbx_extract_batch_device_multi(arr, len(extractors), d_images, row_stride, frame_stride, n_frames, d_kps, d_desc, d_counts, cap,
+                                               stream, 0 if join else 1))
+
+
+def extract_multi_join(extractors, stream=None):
+    arr = (_vp * len(extractors))(*[e.h for e in extractors])
+    _check(lib.orbx_extract_multi_join(arr, len(extractors), stream))
 
 
 class FeatureVectorC(C.Structure):

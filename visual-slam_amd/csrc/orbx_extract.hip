@@ -1703,6 +1703,7 @@ struct orbx_extractor {
 
     hipEvent_t ev[ORBX_STAGE_COUNT + 1] = {};
     hipEvent_t ev_done = nullptr;        // recorded behind the last kernel of every batch, on the stream the batch ran on
+    hipEvent_t ev_fork = nullptr;        // orbx_extract_batch_device_multi: recorded on the caller's stream, waited for by the contexts' streams
     void* sr_dev = nullptr; uint8_t* sr_pin = nullptr; size_t sr_bytes = 0;   // staging of the host form of the stereo refinement
     hipStream_t copy_stream = nullptr;   // uploads of the chunked host batch path
     std::vector<hipEvent_t> chunk_ev;    // one per chunk: upload done
@@ -1833,6 +1834,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<false>), ex->oct_lds));
     HIP_CHECK(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&ex->ev_done, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ex->ev_fork, hipEventDisableTiming));
     const size_t B = (size_t)max_batch;
     HIP_CHECK(hipMalloc(&ex->d_lv, sizeof(DevLevel) * geo.nlevels));
     HIP_CHECK(hipMalloc(&ex->d_cells, sizeof(CellRec) * std::max<size_t>(geo.cells.size(), 1)));
@@ -1917,6 +1919,7 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     if (ex->graph1) (void)hipGraphExecDestroy(ex->graph1);
     for (hipEvent_t e : ex->chunk_ev) (void)hipEventDestroy(e);
     if (ex->ev_done) (void)hipEventDestroy(ex->ev_done);
+    if (ex->ev_fork) (void)hipEventDestroy(ex->ev_fork);
     if (ex->sr_dev) (void)hipFree(ex->sr_dev);
     if (ex->sr_pin) (void)hipHostFree(ex->sr_pin);
     if (ex->copy_stream) (void)hipStreamDestroy(ex->copy_stream);
@@ -2040,6 +2043,57 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, ptrdi
                                  d_counts, cap_per_frame);
     if (rc == ORBX_OK) ex->last_frames = n_frames;
     return rc;
+}
+
+int orbx_extract_batch_device_multi(orbx_extractor* const* exs, int n_contexts, const uint8_t* d_images, ptrdiff_t row_stride,
+                                    ptrdiff_t frame_stride, int n_frames, orbx_keypoint* d_kps, uint8_t* d_desc,
+                                    int32_t* d_counts, int cap_per_frame, void* stream, int flags)
+{
+    if (!exs || n_contexts < 1 || !d_kps || !d_desc || !d_counts || n_frames < 1 || cap_per_frame < 1 || (flags & ~ORBX_MULTI_NO_JOIN)) {
+        set_error("orbx_extract_batch_device_multi: bad argument"); return ORBX_ERR_BAD_ARG;
+    }
+    const int per = (n_frames + n_contexts - 1) / n_contexts;
+    for (int c = 0; c < n_contexts; ++c) {
+        orbx_extractor* ex = exs[c];
+        if (!ex || ex->device != exs[0]->device || ex->geo.width != exs[0]->geo.width || ex->geo.height != exs[0]->geo.height || ex->channels != exs[0]->channels) {
+            set_error("orbx_extract_batch_device_multi: the contexts must share device, image size and input format"); return ORBX_ERR_BAD_ARG;
+        }
+        if (std::min(per, n_frames - c * per) > ex->max_batch) { set_error("orbx_extract_batch_device_multi: a context's share exceeds its max_batch"); return ORBX_ERR_BAD_ARG; }
+        if (d_images && row_stride < (ptrdiff_t)ex->geo.width * ex->channels) { set_error("row_stride < width * channels"); return ORBX_ERR_BAD_ARG; }
+        if (!d_images && ex->channels != 1) { set_error("orbx_extract_batch_device_multi: the input views hold grey frames"); return ORBX_ERR_BAD_ARG; }
+    }
+    HIP_CHECK(hipSetDevice(exs[0]->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    HIP_CHECK(hipStreamIsCapturing(st, &capturing));
+    if (capturing != hipStreamCaptureStatusNone) { set_error("orbx_extract_batch_device_multi: not under stream capture (it orders its streams with events of its own)"); return ORBX_ERR_BAD_ARG; }
+    // fork: what the caller's stream has queued so far (the producer of the frames) comes first on every context's stream
+    HIP_CHECK(hipEventRecord(exs[0]->ev_fork, st));
+    for (int c = 0; c < n_contexts; ++c) {
+        const int f0 = c * per, nf = std::min(per, n_frames - f0);
+        if (nf <= 0) break;
+        orbx_extractor* ex = exs[c];
+        HIP_CHECK(hipStreamWaitEvent(ex->stream, exs[0]->ev_fork, 0));
+        const Geometry& G = ex->geo;
+        const uint8_t* img = d_images ? d_images + (ptrdiff_t)f0 * frame_stride : ex->d_pyr + G.lv[0].roi;
+        const ptrdiff_t rs = d_images ? row_stride : (ptrdiff_t)G.lv[0].stride, fs = d_images ? frame_stride : (ptrdiff_t)G.pyr_bytes;
+        const int rc = launch_frames(ex, ex->stream, 0, nf, false, img, rs, fs, d_kps + (size_t)f0 * cap_per_frame,
+                                     d_desc + (size_t)f0 * cap_per_frame * 32, d_counts + f0, cap_per_frame);
+        if (rc) return rc;
+        ex->last_frames = nf;
+        // join: the caller's stream continues behind this context's last kernel
+        if (!(flags & ORBX_MULTI_NO_JOIN)) HIP_CHECK(hipStreamWaitEvent(st, ex->ev_done, 0));
+    }
+    return ORBX_OK;
+}
+
+int orbx_extract_multi_join(orbx_extractor* const* exs, int n_contexts, void* stream)
+{
+    if (!exs || n_contexts < 1) { set_error("orbx_extract_multi_join: bad argument"); return ORBX_ERR_BAD_ARG; }
+    for (int c = 0; c < n_contexts; ++c) if (!exs[c]) { set_error("orbx_extract_multi_join: null context"); return ORBX_ERR_BAD_ARG; }
+    HIP_CHECK(hipSetDevice(exs[0]->device));
+    for (int c = 0; c < n_contexts; ++c) HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, exs[c]->ev_done, 0));
+    return ORBX_OK;
 }
 
 int orbx_extractor_set_input_format(orbx_extractor* ex, int format)
