@@ -548,6 +548,10 @@ def worker(a):
     C = len(job.exs)
     t_extract = cx.timed(job.step, a.steps, a.warmup)
     fps = n_gpus * B * a.steps / t_extract
+    # how much the figure moves from one timed region to the next on this box (clock state, other tenants): three more
+    # regions of the same length (at most 50 steps each), reported beside the headline, never instead of it
+    rsteps = min(a.steps, 50)
+    repeats = [n_gpus * B * rsteps / cx.timed(job.step, rsteps, 0) for _ in range(3)]
     mean_kp = job.mean_kp()
     frames, kps, desc, counts, cap, uniq = job.frames, job.kps, job.desc, job.counts, job.cap, job.uniq
     # the same step with the frames in a plain buffer of the caller's (row stride = width): every launch then starts
@@ -670,6 +674,7 @@ def worker(a):
                                    f"{B} HBM-resident frames per GPU per step (BASELINE configs[0] shape, batched)",
                        "input": "frames resident in the extractors' input views (orbx_extractor_input_view: level 0 of the pyramid, "
                                 "no copy at the start of a launch); copy_input_value is the same step from a plain width-strided buffer",
+                       "repeat_values": [round(v) for v in repeats],   # three more timed regions of the headline step: run-to-run spread on this box
                        "copy_input_value": fps_copy,
                        "one_call_value": fps_one_call,      # the same contexts behind one call on one caller stream (orbx_extract_batch_device_multi)
                        "one_call_no_join_value": fps_one_call_nojoin,   # ... with ORBX_MULTI_NO_JOIN: calls queued back to back, joined once at the end
