@@ -55,6 +55,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the stereo / 1241x376 / 3840x2160 legs")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="headline and brute-force legs only: no copy-input / one-call / one-context legs and no matcher leg on extracted "
+                         "descriptors (profiling runs: every extraction launch in the trace then has the headline's size)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry", action="store_true",
                     help="no GPU work: ranks rendezvous, exchange and merge stand-in records (launcher / collective rehearsal on CPU)")
@@ -558,8 +561,10 @@ def worker(a):
     # with the library's copy into the padded level 0, as ComputePyramid does (src/ORBextractor.cc:1124-1128)
     job.input_view = False
     csteps = max(2, a.steps // 4)
-    t_copy = cx.timed(job.step, csteps, min(a.warmup, 3))
-    fps_copy = n_gpus * B * csteps / t_copy
+    fps_copy = fps_solo = None
+    if not a.no_extra_legs:
+        t_copy = cx.timed(job.step, csteps, min(a.warmup, 3))
+        fps_copy = n_gpus * B * csteps / t_copy
     # one caller stream, one call per step: orbx_extract_batch_device_multi spreads the batch over the same contexts and
     # joins them on the caller's stream (frames in the input views, as in the headline)
     one_stream = torch.cuda.current_stream().cuda_stream
@@ -571,16 +576,17 @@ def worker(a):
         vsa.extract_batch_device_multi(job.exs, None, 0, 0, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, one_stream, join=False)
 
     fps_one_call = fps_one_call_nojoin = None
-    if C > 1 and job.per == job.chunk:
+    if C > 1 and job.per == job.chunk and not a.no_extra_legs:
         t_one = cx.timed(one_call_step, csteps, min(a.warmup, 3))
         fps_one_call = n_gpus * B * csteps / t_one
         t_one = cx.timed(one_call_nojoin_step, csteps, min(a.warmup, 3))     # the barrier's device synchronise is the join
         fps_one_call_nojoin = n_gpus * B * csteps / t_one
     # ... and a single context on a single stream working through the same batch in launches of the same size
-    solo = ExtractJob(cx, vsa, np, p, W, H, job.chunk, 1, job.chunk, seed0=rank * 100000, stereo_right=None)
-    t_solo = cx.timed(solo.step, csteps * 2, min(a.warmup, 3))
-    fps_solo = n_gpus * job.chunk * csteps * 2 / t_solo
-    solo.close()
+    if not a.no_extra_legs:
+        solo = ExtractJob(cx, vsa, np, p, W, H, job.chunk, 1, job.chunk, seed0=rank * 100000, stereo_right=None)
+        t_solo = cx.timed(solo.step, csteps * 2, min(a.warmup, 3))
+        fps_solo = n_gpus * job.chunk * csteps * 2 / t_solo
+        solo.close()
     job.close()
 
     # per-stage device time: HIP events recorded by the library on the launch stream around each stage, one launch of
@@ -589,11 +595,14 @@ def worker(a):
     ex = vsa.Extractor(p, W, H, max_batch=PB, device=cx.local)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def profiled_step():
-        ex.extract_batch_device(frames.data_ptr(), W, W * H, PB, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+    src = [frames.data_ptr(), W, W * H]
 
-    profiled_step()
+    def profiled_step():
+        ex.extract_batch_device(src[0], src[1], src[2], PB, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+
+    profiled_step()                      # from the plain buffer: its copy kernel leaves the frames in the input view ...
     torch.cuda.synchronize()
+    src[:] = ex.input_view()             # ... which the measured steps read, as the headline does
     ex.set_profiling(True)
     stage_ms = np.zeros(len(vsa.STAGES))
     prof_steps = max(3, min(a.steps, 10))
@@ -657,7 +666,8 @@ def worker(a):
     if not a.no_hamming:
         hamming = leg_hamming(cx, vsa, np, a, max(2, min(a.steps, 40)), min(a.warmup, 3))
         torch.cuda.empty_cache()
-        hamming["extracted_descriptors"] = leg_hamming_extracted(cx, vsa, np, max(2, min(a.steps, 40)), min(a.warmup, 3))
+        if not a.no_extra_legs:
+            hamming["extracted_descriptors"] = leg_hamming_extracted(cx, vsa, np, max(2, min(a.steps, 40)), min(a.warmup, 3))
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     cpu = None

@@ -10,7 +10,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 stamp=$(python3 -c "import importlib; print(importlib.import_module('visual-slam_amd').build_stamp())") || exit 1
 echo "build stamp $stamp" | tee $out/STAMP
-B="--contexts 1 --batch 256 --no-cpu-baseline --no-configs"
+B="--contexts 1 --batch 256 --no-cpu-baseline --no-configs --no-extra-legs"
 kt() { # name, title, command...
   name=$1; title=$2; shift 2
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name -- "$@" > $out/$name.json 2> $out/$name.err || { echo "trace $name failed"; tail -3 $out/$name.err; return 1; }
@@ -25,8 +25,8 @@ pmc() { # name, counters, bench args...
   echo "pass $name ok"
 }
 kt kt "bench.py $B --steps 10 (every extraction launch covers 256 frames of 640x480; k_best2_mfma: 4096 queries x 2^24 rows)" python3 bench.py $B --steps 10 || exit 1
-kt kt4ctx "bench.py --no-cpu-baseline --no-configs --no-hamming --steps 10 (the default: 1024 frames per step on four contexts, 256 frames per launch)" python3 bench.py --no-cpu-baseline --no-configs --no-hamming --steps 10 || exit 1
-kt kt_uhd "bench.py $B --no-hamming --width 3840 --height 2160 --nfeatures 8000 --nlevels 12 --batch 64 --steps 4" python3 bench.py --contexts 1 --no-cpu-baseline --no-configs --no-hamming --width 3840 --height 2160 --nfeatures 8000 --nlevels 12 --batch 64 --steps 4 --warmup 1 || exit 1
+kt kt4ctx "bench.py --no-cpu-baseline --no-configs --no-hamming --steps 10 (the default: 1024 frames per step on four contexts, 256 frames per launch)" python3 bench.py --no-cpu-baseline --no-configs --no-hamming --no-extra-legs --steps 10 || exit 1
+kt kt_uhd "bench.py $B --no-hamming --width 3840 --height 2160 --nfeatures 8000 --nlevels 12 --batch 64 --steps 4" python3 bench.py --contexts 1 --no-cpu-baseline --no-configs --no-hamming --no-extra-legs --width 3840 --height 2160 --nfeatures 8000 --nlevels 12 --batch 64 --steps 4 --warmup 1 || exit 1
 kt kt_stereo "tools/stereo_bench.py (128 pairs of 752x480, 1200 features, left and right contexts, row search + SAD refinement)" python3 tools/stereo_bench.py || exit 1
 pmc pmc_rd "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" --no-hamming || exit 1
 pmc pmc_wr "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum" --no-hamming || exit 1

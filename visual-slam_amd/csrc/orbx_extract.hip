@@ -236,6 +236,48 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img,
     store_chunk_with_frame(pyr + (unsigned long long)frame * pyr_bytes + L.roi, L.stride, L.h, y, ch, v);
 }
 
+// Level 0 already in place (the frames were written into the context's input view): only the part of the REFLECT_101
+// frame that later stages read is missing.  Per frame: threads 0 .. h-1 take one ROI row each (the dword left of it repeats
+// columns 4..1, the three pixels right of it repeat columns w-2..w-4, written as the two dwords that hold them), then
+// 6 * cpr threads copy the three rows above and below the ROI (rows 1..3 and h-2..h-4 with the side pixels they were just
+// given -- by other threads, so those six rows get their side pixels computed here again, not read back).
+__global__ __launch_bounds__(256) void k_level0_frame(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L, int n_frames)
+{
+    int frame; uint32_t blk;
+    if (!frame_chunk(n_frames, frame, blk)) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    uint8_t* roi = pyr + (unsigned long long)frame * pyr_bytes + L.roi;
+    const uint32_t nside = (uint32_t)L.h, ncopy = 6u * (uint32_t)L.cpr;
+    if (i < nside) {
+        uint8_t* row = roi + (unsigned long long)i * L.stride;
+        const uint2 a = *reinterpret_cast<const uint2*>(row);                       // columns 0..7 (rows are 32-byte aligned)
+        *reinterpret_cast<uint32_t*>(row - 4) = __builtin_amdgcn_perm(a.y, a.x, 0x01020304u);
+        // columns w .. w+2 = columns w-2, w-3, w-4; the bytes around them (the ROI's last columns, the column after) are kept
+        uint8_t t[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = row[L.w - 2 - k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) row[L.w + k] = t[k];
+    } else if (i < nside + ncopy) {
+        const uint32_t j = i - nside, r = j / (uint32_t)L.cpr, ch = j - r * (uint32_t)L.cpr;     // r 0..2: above, 3..5: below
+        const int src = r < 3 ? (int)r + 1 : L.h - 2 - (int)(r - 3), dst = r < 3 ? -(int)r - 1 : L.h + (int)(r - 3);
+        const uint8_t* srow = roi + (long long)src * L.stride;
+        uint8_t* drow = roi + (long long)dst * L.stride;
+        uint4 v = *reinterpret_cast<const uint4*>(srow + 16 * ch);
+        if ((int)(16 * ch + 16) > L.w) {                                           // the chunk reaches the frame columns right of the ROI
+            uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int x = (int)(16 * ch) + k;
+                if (x >= L.w && x < L.w + kFrameFill) w4[k >> 2] = (w4[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)srow[2 * L.w - 2 - x] << (8 * (k & 3)));
+            }
+            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        *reinterpret_cast<uint4*>(drow + 16 * ch) = v;
+        if (ch == 0) *reinterpret_cast<uint32_t*>(drow - 4) = __builtin_amdgcn_perm(v.y, v.x, 0x01020304u);
+    }
+}
+
 // Level l from level l-1: cv::resize INTER_LINEAR for 8-bit (Q11 weights, two-stage rounding).
 // A thread owns one group of four adjacent destination columns over four consecutive rows, and consecutive
 // lanes own consecutive groups, so each load or store of a wavefront touches a few cache lines.  The four
@@ -1949,8 +1991,8 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
         dim3 grid(frame_chunk_grid((L0.cpr * L0.h + 255) / 256, B));
         if (ex->channels == 1 && d_images == pyr + L0.roi && row_stride == (ptrdiff_t)L0.stride && frame_stride == (ptrdiff_t)G.pyr_bytes) {
             // the frames already lie where level 0 lives (orbx_extractor_input_view): no copy, only the REFLECT_101 frame
-            dim3 gb((border_threads(L0.w, L0.h, L0.stride, kFrameFill, 1, 2) + 255) / 256, 1, B);
-            hipLaunchKernelGGL(k_borders, gb, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->d_lv, kFrameFill, 1, 2);
+            hipLaunchKernelGGL(k_level0_frame, frame_chunk_grid((unsigned)((L0.h + 6 * L0.cpr + 255) / 256), B), dim3(256), 0, st, pyr,
+                               (unsigned long long)G.pyr_bytes, L0, B);
         } else if (ex->channels == 1)
             hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
                                pyr, (unsigned long long)G.pyr_bytes, L0, B);
