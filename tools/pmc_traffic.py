@@ -36,7 +36,10 @@ for k, d in mean.items():
     if "SQ_INSTS_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
         kern[k]["valu_issue_frac"] = round(d["SQ_INSTS_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 3)
 tot = lambda k, n=1: n * (kern.get(k, {}).get("read_bytes", 0) + kern.get(k, {}).get("write_bytes", 0))
-stages = {"pyramid": tot("k_level0") + tot("k_resize", resizes) + tot("k_borders"), "fast": tot("k_fast_cells"),
+# level 0: the batches of the timed region read their frames from the input view, where only the frame kernel runs (the copy kernel
+# appears in the passes once, when the view is filled)
+level0 = tot("k_level0_frame") if "k_level0_frame" in kern else tot("k_level0")
+stages = {"pyramid": level0 + tot("k_resize", resizes) + tot("k_borders"), "fast": tot("k_fast_cells"),
           "octree": tot("k_octree"), "describe": tot("k_blur") + tot("k_describe")}
 json.dump({"build_stamp": stamp, "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_WRITE_DRAM_32B_sum over "
                      "bench.py --contexts 1 (640x480, 256 frames per launch); k_resize is the mean of its launches "
