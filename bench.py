@@ -614,7 +614,7 @@ def worker(a):
     ex.close()
 
     sum_p, a_extract = alg_bytes_per_image(vsa, p, W, H, mean_kp)
-    stage_bytes = {"pyramid": 2 * sum_p, "fast": sum_p, "octree": 0, "describe": 2 * sum_p + mean_kp * 2178}
+    stage_bytes = {"pyramid": 2 * sum_p, "fast": sum_p, "octree": 0, "blur": 2 * sum_p, "describe": mean_kp * 2178}
     stages = {}
     for i, name in enumerate(vsa.STAGES):
         ms = float(stage_ms[i])
@@ -634,9 +634,10 @@ def worker(a):
             traffic_src = f"profiles/traffic.json is stale (taken on build {tj.get('build_stamp')}, library is {vsa.build_stamp()})"
         elif dom in tj.get("stages", {}):
             traffic, traffic_src = tj["stages"][dom], tj.get("source")
-            dom_kernel = {"fast": "k_fast_cells", "octree": "k_octree"}.get(dom)
+            dom_kernel = {"fast": "k_fast_cells", "octree": "k_octree", "blur": "k_blur", "describe": "k_describe"}.get(dom)
             valu_issue = tj.get("kernels_mean_per_launch", {}).get(dom_kernel, {}).get("valu_issue_frac") if dom_kernel else None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+    kernel_of = {"pyramid": "k_level0_frame + k_resize per level", "fast": "k_fast_cells", "octree": "k_octree", "blur": "k_blur", "describe": "k_describe"}
+    roofline = {"bound": "hbm", "kernel": kernel_of[dom], "stage": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(stage_bytes[dom] * PB), "launch_ms": round(dom_ms, 4),
                 "valu_issue_frac": valu_issue,   # vector instructions x 4 cycles / SIMD cycles: an upper estimate of the issue pipe's load (2 to 4.5 cycles each on this chip)

@@ -193,7 +193,7 @@ int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, in
 
 /* Per-stage device time of the last batch, measured with HIP events on the launch stream when
  * profiling is switched on (no counterpart in the reference).  Stage order: ORBX_STAGE_*. */
-enum { ORBX_STAGE_PYRAMID = 0, ORBX_STAGE_FAST = 1, ORBX_STAGE_OCTREE = 2, ORBX_STAGE_DESCRIBE = 3, ORBX_STAGE_COUNT = 4 };
+enum { ORBX_STAGE_PYRAMID = 0, ORBX_STAGE_BLUR = 1, ORBX_STAGE_FAST = 2, ORBX_STAGE_OCTREE = 3, ORBX_STAGE_DESCRIBE = 4, ORBX_STAGE_COUNT = 5 };
 int orbx_extractor_set_profiling(orbx_extractor* ex, int on);
 int orbx_extractor_stage_ms(orbx_extractor* ex, float* ms /* ORBX_STAGE_COUNT */);
 

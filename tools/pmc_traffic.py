@@ -40,7 +40,7 @@ tot = lambda k, n=1: n * (kern.get(k, {}).get("read_bytes", 0) + kern.get(k, {})
 # appears in the passes once, when the view is filled)
 level0 = tot("k_level0_frame") if "k_level0_frame" in kern else tot("k_level0")
 stages = {"pyramid": level0 + tot("k_resize", resizes) + tot("k_borders"), "fast": tot("k_fast_cells"),
-          "octree": tot("k_octree"), "describe": tot("k_blur") + tot("k_describe")}
+          "octree": tot("k_octree"), "blur": tot("k_blur"), "describe": tot("k_describe")}
 json.dump({"build_stamp": stamp, "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_WRITE_DRAM_32B_sum over "
                      "bench.py --contexts 1 (640x480, 256 frames per launch); k_resize is the mean of its launches "
                      f"times {resizes}", "kernels_mean_per_launch": kern, "stages": stages}, open(out, "w"), indent=1)

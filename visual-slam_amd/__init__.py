@@ -17,7 +17,7 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 BEST2_DTYPE = np.dtype([("best", "<i4"), ("best_idx", "<i4"), ("second", "<i4"), ("pad", "<i4")])
 assert KEYPOINT_DTYPE.itemsize == 28 and BEST2_DTYPE.itemsize == 16
 
-STAGES = ("pyramid", "fast", "octree", "describe")
+STAGES = ("pyramid", "blur", "fast", "octree", "describe")
 
 
 class Params(C.Structure):
