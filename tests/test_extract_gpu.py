@@ -182,6 +182,28 @@ def test_noise_images(vsa, oracle):
         ex.close(); oex.close()
 
 
+def test_clustered_corners_leave_the_quadtree_tables(vsa, oracle):
+    """Levels whose candidates do not fit the quadtree's LDS key arrays are selected from without a dense key copy, on
+    the count tables alone, as long as the split steps stay above the tables' depth.  A frame whose corners sit in one
+    small patch sends the steps far below it: the kernel must notice and take the dense form, with the same result.
+    Shapes whose level 0 has thousands of candidates in a patch (noise) on a flat or on an ordinary background."""
+    rng = np.random.default_rng(123)
+    for w, h, nf, patch, background in [(1241, 376, 2000, (60, 200, 300, 560), "flat"), (1241, 376, 2000, (100, 260, 700, 980), "scene"),
+                                        (1920, 1080, 4000, (400, 640, 800, 1200), "flat"), (1920, 1080, 4000, (0, 1080, 0, 1920), "scene")]:
+        img = np.full((h, w), 117, np.uint8) if background == "flat" else vsa.synth_frame(31, w, h).copy()
+        y0, y1, x0, x1 = patch
+        if background == "flat" or (y1 - y0) < h:
+            img[y0:y1, x0:x1] = rng.integers(0, 256, (y1 - y0, x1 - x0), dtype=np.uint8)
+        ex = vsa.Extractor(vsa.make_params(nf, 1.2, 8, 20, 7), w, h, max_batch=1, device=0)
+        oex = oracle.Extractor(oracle.make_params(nf, 1.2, 8, 20, 7))
+        kps, desc = ex.extract(img)
+        okps, odesc = oex.extract(img, cap=nf + 64 * 8)
+        assert len(oex.level_candidates(0)[0]) > 3000, (w, h, background)
+        assert len(kps) == len(okps) > 0, (w, h, background)
+        assert np.array_equal(kps, okps.astype(vsa.KEYPOINT_DTYPE)) and np.array_equal(desc, odesc), (w, h, background)
+        ex.close(); oex.close()
+
+
 def test_constant_image_gives_no_keypoints(vsa):
     w, h = 320, 240
     ex = vsa.Extractor(vsa.make_params(500, 1.2, 4), w, h, device=0)

@@ -18,6 +18,8 @@ def load_sim():
     lib = C.CDLL(path)
     lib.otsim_distribute.restype = C.c_int
     lib.otsim_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    lib.otsim_distribute_direct.restype = C.c_int
+    lib.otsim_distribute_direct.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     return lib
 
 
@@ -26,6 +28,7 @@ def test_parallel_formulation_equals_list_version(oracle, vsa):
     rng = np.random.default_rng(11)
     checked = 0
     sweeps = {}
+    direct = {"done": 0, "fallback": 0, "no_tables": 0}
     for it in range(300):
         W, H = int(rng.integers(60, 1300)), int(rng.integers(60, 520))
         if it % 9 == 0:
@@ -61,8 +64,23 @@ def test_parallel_formulation_equals_list_version(oracle, vsa):
             lib.otsim_sweeps(C.byref(a), C.byref(b), 1)
             t = sweeps.setdefault(table_cap if table_cap <= 0 else 1, [0, 0])
             t[0] += a.value; t[1] += b.value
+        # the direct form (no dense key array: count, steps on the tables alone, leaf table, (cell, index) ranks): the same
+        # selection wherever its steps stay on the tables; -1 is the kernel's cue to take the dense form instead
+        for table_cap in (-1, 90 * round(W / H)):
+            out = np.zeros(cap, np.uint32)
+            m = lib.otsim_distribute_direct(keys.ctypes.data, len(keys), 16, 16 + W, 16, 16 + H, N, out.ctypes.data, cap, table_cap, 1 + it % 23)
+            lib.otsim_sweeps(C.byref(C.c_int()), C.byref(C.c_int()), 1)
+            if m == -3:
+                direct["no_tables"] += 1
+            elif m == -1:
+                direct["fallback"] += 1
+            else:
+                direct["done"] += 1
+                assert m == len(sel), (it, W, H, len(pts), N, table_cap)
+                assert np.array_equal(out[:m], keys[sel]), (it, W, H, len(pts), N, table_cap)
         checked += 1
     assert checked > 250
+    assert direct["done"] > 150 and direct["fallback"] > 10, direct      # (half of these key sets are clustered on purpose)
     # steps (coarse sweeps and fine steps) run on the tables / walking the keys: the library's table size covers most of
     # them even for these clustered sets, whose fine steps go far below the tables' depth; without tables all walk the keys
     assert sweeps[0][0] == 0 and sweeps[-1][0] > sweeps[-1][1], sweeps

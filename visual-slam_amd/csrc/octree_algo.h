@@ -701,4 +701,88 @@ static OT_DEV int ot_distribute(OtShared& s, KS& ks, const uint32_t* keys,
     return n;
 }
 
+// The steps of DistributeOctTree on the count tables alone, for a caller that counts, hands over and ranks the keys
+// itself: on entry the tables' deepest level (depth D > 0) holds the key counts of its cells.  Runs the same steps as
+// ot_distribute does while it is on its tables and then writes, for every cell of depth D that holds a key, the list
+// position of the node its keys belong to (leaf[cell]: the first cell on the way down from the root that is a node of
+// the final list).  The winner of a node is then the largest (response, first in input order) among the keys that map
+// to it, whether the node holds one key or many.  Returns the length of the list, or -1 when a step would have to
+// split nodes of depth D (clustered keys): such a level goes through ot_distribute with its keys instead.
+static OT_DEV int ot_distribute_tables(OtShared& s, int H, int nIni, float hX, int N, int D, uint16_t* leaf)
+{
+    const int tid = OT_TID, nt = OT_NT;
+    uint16_t* pc = s.ent0;
+    uint16_t* pn = s.ent1;
+    OtMemKeys ks{nullptr, nullptr, 0};        // steps on the tables never touch a key
+    for (int i = tid; i < nIni; i += nt) {
+        OtNode r;
+        r.x0 = (int16_t)(int)(hX * (float)i);
+        r.x1 = (int16_t)(int)(hX * (float)(i + 1));
+        r.y0 = 0; r.y1 = (int16_t)H;
+        r.cnt = 0; r.aux = (uint32_t)i;
+        s.nxt[i] = r;
+    }
+    if (tid == 0) { s.scal[OT_SEQ] = nIni; }
+    const int offD = ot_table_off(nIni, D), cellsD = ot_table_size(nIni, D) - offD;
+    OT_SYNC();
+    for (int d = D - 1; d >= 0; --d) {
+        const int32_t* below = s.tcnt + ot_table_off(nIni, d + 1);
+        int32_t* here = s.tcnt + ot_table_off(nIni, d);
+        const int cells = ot_table_size(nIni, d) - ot_table_off(nIni, d);
+        for (int i = tid; i < cells; i += nt) here[i] = below[4 * i] + below[4 * i + 1] + below[4 * i + 2] + below[4 * i + 3];
+        OT_SYNC();
+    }
+    // drop empty roots (:571-584)
+    for (int i = tid; i < nIni; i += nt) { s.nxt[i].cnt = s.tcnt[i]; s.keep[i] = s.tcnt[i] > 0 ? 1 : 0; }
+    OT_SYNC();
+    const int n0 = ot_block_scan(s.keep, nIni, s.scanTmp);
+    for (int i = tid; i < nIni; i += nt)
+        if (s.nxt[i].cnt > 0) { s.cur[s.keep[i]] = s.nxt[i]; pc[s.keep[i]] = (uint16_t)i; }
+    if (tid == 0) s.scal[OT_N] = n0;
+    OT_SYNC();
+    // main loop (:593-738), as in ot_distribute
+    bool finish = n0 == 0;
+    int sweeps = 0;
+    while (!finish) {
+        const int prevSize = s.scal[OT_N];
+        OT_SYNC();
+        if (sweeps == D) return -1;
+        ot_coarse_step<true>(s, ks, sweeps, nIni, pc, pn);
+        { uint16_t* t = pc; pc = pn; pn = t; }
+        { OtNode* t = s.cur; s.cur = s.nxt; s.nxt = t; }
+        ++sweeps;
+        const int n = s.scal[OT_N], nToExpand = s.scal[OT_NEXP];
+        if (n >= N || n == prevSize) finish = true;
+        else if (n + nToExpand * 3 > N) {
+            while (!finish) {
+                const int prev2 = s.scal[OT_N];
+                OT_SYNC();
+                if (sweeps == D) return -1;
+                ot_split_step<true>(s, ks, N, 1, sweeps, nIni, pc, pn);
+                { uint16_t* t = pc; pc = pn; pn = t; }
+                { OtNode* t = s.cur; s.cur = s.nxt; s.nxt = t; }
+                ++sweeps;
+                const int n2 = s.scal[OT_N];
+                if (n2 >= N || n2 == prev2) finish = true;
+            }
+        }
+    }
+    OT_SYNC();
+    const int n = s.scal[OT_N];
+    for (int p = tid; p < n; p += nt) s.tpos[pc[p]] = (uint16_t)p;
+    OT_SYNC();
+    for (int i = tid; i < cellsD; i += nt) {
+        if (s.tcnt[offD + i] == 0) continue;
+        int off = 0, cells = nIni;
+        for (int d = 0; d <= D; ++d) {
+            const int e = off + (i >> (2 * (D - d)));
+            const int pos = s.tpos[e];
+            if (s.tcnt[e] == 1 || pos != 0xFFFF) { leaf[i] = (uint16_t)pos; break; }
+            off += cells; cells *= 4;
+        }
+    }
+    OT_SYNC();
+    return n;
+}
+
 } // namespace orbx
