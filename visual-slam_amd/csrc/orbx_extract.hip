@@ -329,20 +329,25 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
         sel[k] = (off | (off << 16)) + 0x0c010c00u;                             // bytes off, off+1 -> 16-bit lanes 0, 1
     }
     // all products below fit 24-bit operands: rows < 2^15, strides < 2^13, weights <= 2048, sums >> 4 < 2^15
-    const uint32_t shift = (uint32_t)(int)ta.x & 3u;                            // level origins and strides are multiples of 32
-    const uint8_t* scol = base + S.roi + ((int)ta.x - (int)shift);
-    uint8_t* dcol = base + D.roi + 4 * ((int)gx - 1);
+    // addresses: a wavefront-uniform base plus an unsigned 32-bit lane offset, so that no load or store needs 64-bit vector
+    // arithmetic (a tenth of the kernel's vector instructions otherwise).  First source columns are never negative (frame
+    // groups repeat their mirror column); the destination base sits kFrameFill rows and one group left / above the ROI.
+    const uint32_t shift = ta.x & 3u;                                           // level origins and strides are multiples of 32
+    const uint8_t* sbase = base + S.roi;
+    const uint32_t scol = ta.x - shift;
+    uint8_t* dbase = base + D.roi - 4 - (long long)kFrameFill * D.stride;
+    const uint32_t dcol = 4u * gx + (uint32_t)kFrameFill * (uint32_t)D.stride;
     const int y0 = (int)rb * kResizeRows;
     uint2 r0[kResizeRows], r1[kResizeRows];
     uint32_t b0[kResizeRows], b1[kResizeRows];
     if constexpr (kSharedRows) {
         const uint4 tr = *reinterpret_cast<const uint4*>(rrb + D.rb_offset + rb);
         const uint32_t rec[4] = {tr.x, tr.y, tr.z, tr.w};
-        const int sbase = (int)((tr.x >> 25) | ((tr.y >> 25) << 7) | ((tr.z >> 25) << 14));
+        const int srow0 = (int)((tr.x >> 25) | ((tr.y >> 25) << 7) | ((tr.z >> 25) << 14));
         uint2 rows[kResizeRows + 2];
 #pragma unroll
         for (int k = 0; k < kResizeRows + 2; ++k)
-            rows[k] = resize_window(scol + __umul24((uint32_t)min(sbase + k, S.h - 1), (uint32_t)S.stride), shift);
+            rows[k] = resize_window(sbase + (scol + __umul24((uint32_t)min(srow0 + k, S.h - 1), (uint32_t)S.stride)), shift);
 #pragma unroll
         for (int r = 0; r < kResizeRows; ++r) {
             const bool up = rec[r] & (1u << 24);
@@ -357,8 +362,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
         for (int r = 0; r < kResizeRows; ++r) ey[r] = ryt[D.ry_offset + min(y0 + r, D.h - 1)];
 #pragma unroll
         for (int r = 0; r < kResizeRows; ++r) {
-            r0[r] = resize_window(scol + __umul24((uint32_t)ey[r].sy0, (uint32_t)S.stride), shift);
-            r1[r] = resize_window(scol + __umul24((uint32_t)ey[r].sy1, (uint32_t)S.stride), shift);
+            r0[r] = resize_window(sbase + (scol + __umul24((uint32_t)ey[r].sy0, (uint32_t)S.stride)), shift);
+            r1[r] = resize_window(sbase + (scol + __umul24((uint32_t)ey[r].sy1, (uint32_t)S.stride)), shift);
             b0[r] = (uint32_t)(int)ey[r].b0; b1[r] = (uint32_t)(int)ey[r].b1;
         }
     }
@@ -385,10 +390,11 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
         const int y = y0 + r;
         if (y >= D.h) break;
         const uint32_t v = out[r];
-        *reinterpret_cast<uint32_t*>(dcol + __umul24((uint32_t)y, (uint32_t)D.stride)) = v;
+        *reinterpret_cast<uint32_t*>(dbase + (dcol + __umul24((uint32_t)y, (uint32_t)D.stride))) = v;
         // frame row -j repeats row j, row h-1+j repeats row h-1-j (j = 1..kFrameFill)
         const bool top = (uint32_t)(y - 1) < (uint32_t)kFrameFill, bottom = (uint32_t)(D.h - 2 - y) < (uint32_t)kFrameFill;
-        if (top || bottom) *reinterpret_cast<uint32_t*>(dcol + (long long)__mul24(top ? -y : 2 * (D.h - 1) - y, D.stride)) = v;
+        if (top || bottom)
+            *reinterpret_cast<uint32_t*>(dbase + (4u * gx + __umul24((uint32_t)(kFrameFill + (top ? -y : 2 * (D.h - 1) - y)), (uint32_t)D.stride))) = v;
     }
 }
 
