@@ -689,20 +689,30 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
     const int cw = c.cw, ch = c.ch;
     const int tw = cw + 6, th = ch + 6;
     {
-        // 16 bytes per lane, TS/16 lanes per tile row
-        constexpr int LPR = TS / 16, RPI = 64 / LPR;
-        const int r0 = lane / LPR, j = lane - r0 * LPR;
-        if (lane < LPR * RPI && 16 * j < tw)
-            for (int r = r0; r < th; r += RPI) {
-                const u128_unaligned t = *reinterpret_cast<const u128_unaligned*>(src + ((uint32_t)r * c.stride + 16u * (uint32_t)j));
-                *reinterpret_cast<uint4*>(tile + r * TS + 16 * j) = make_uint4(t.x, t.y, t.z, t.w);
-            }
+        // 16 bytes per lane, TS/16 lanes per tile row, RPI rows per turn: at most NIT turns, written out so that every load
+        // is issued before the first store and the addresses are a uniform base plus a 32-bit lane offset (left to itself
+        // the compiler unrolls the loop eightfold around 64-bit multiply-adds)
+        constexpr int LPR = TS / 16, RPI = 64 / LPR, NIT = (TR + RPI - 1) / RPI;
+        const int r0 = (int)(__umul24((uint32_t)lane, (256u + LPR - 1) / LPR) >> 8), j = lane - (LPR == 3 ? r0 + (r0 << 1) : r0 + (r0 << 2));   // lane / LPR (exact for lane < 64, LPR 3 or 5)
+        static_assert(LPR == 3 || LPR == 5, "the reciprocal above is checked for these");
+        const bool act = lane < LPR * RPI && 16 * j < tw;
+        const uint32_t goff = __umul24((uint32_t)r0, c.stride) + 16u * (uint32_t)j, gstep0 = (uint32_t)RPI * c.stride;
+        uint32_t gstep = gstep0, gstep2 = 2u * gstep0;
+        asm volatile("" : "+s"(gstep), "+s"(gstep2));      // (kept as scalars: folded back into the offsets they become 64-bit multiply-adds)
+        const uint32_t loff = (uint32_t)(r0 * TS + 16 * j);
+        u128_unaligned t[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (act && r0 + it * RPI < th) t[it] = *reinterpret_cast<const u128_unaligned*>(src + (goff + (it == 0 ? 0u : it == 1 ? gstep : it == 2 ? gstep2 : (uint32_t)it * gstep)));
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (act && r0 + it * RPI < th) *reinterpret_cast<uint4*>(tile + (loff + (uint32_t)(it * RPI * TS))) = make_uint4(t[it].x, t[it].y, t[it].z, t[it].w);
     }
     FSTAMP(0);
     // pretest lanes: groups of four pixels, gpr per row (<= 15), as many whole rows per round as 64 lanes hold
     const int gpr = (cw + 3) >> 2;
     const int rows_per_round = kGroupsPerRow.rows[gpr];              // 64 / gpr
-    const int lrow = (lane * kGroupsPerRow.magic[gpr]) >> 16;        // lane / gpr (exact for lane < 64, gpr <= 15)
+    const int lrow = (int)(__umul24((uint32_t)lane, (uint32_t)kGroupsPerRow.magic[gpr]) >> 16);   // lane / gpr (exact for lane < 64, gpr <= 15)
     const int g = lane - lrow * gpr;
     const int x = 4 * g;
     const int npx = lrow < rows_per_round ? min(cw - x, 4) : 0;            // pixels of the lane inside the cell
@@ -818,8 +828,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
         const int rstep = rows_per_round * 64;
         const int qb0 = qbase - (kRoundBits - R) * rstep;
         auto lowest = [](Bits bits) -> int { return sizeof(Bits) == 4 ? __ffs((int)bits) - 1 : __ffsll((long long)bits) - 1; };
+        // (the multiply-add spelled out: the compiler knows both factors are small, drops the 24-bit form and then picks
+        // the 64-bit multiply-add, which issues at a quarter of the rate, for the innermost loop of the queueing)
         auto entry_of = [&](int bpos) -> uint16_t {
-            return (uint16_t)(qb0 + (int)__umul24((uint32_t)(bpos & (kRoundBits - 1)), (uint32_t)rstep) + (bpos >> (kSmall ? 3 : 4)));
+            uint32_t e;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(e) : "v"((uint32_t)(bpos & (kRoundBits - 1))), "s"((uint32_t)rstep), "v"((uint32_t)(qb0 + (bpos >> (kSmall ? 3 : 4)))));
+            return (uint16_t)e;
         };
         auto enqueue = [&](Bits bits, int off) {
             while (bits) {
@@ -866,10 +880,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
                 score_queued(n, T);
                 wave_sync();
             }
-            for (int i = lane; i < cw * ch; i += 64) {
-                const int yy = i / cw, xx = i - yy * cw;
-                if (score[(yy + 1) * SS + xx + 1] && strict_max(yy, xx)) atomicOr(&rowmask[yy], 1ull << xx);
-            }
+            // (row by row, a lane per column -- cells are under 64 wide: a flat index would cost every cell, dense or not,
+            // the set-up of a division by the cell width, which the compiler moves to the top of the kernel)
+            for (int yy = 0; yy < ch; ++yy)
+                if (lane < cw && score[(yy + 1) * SS + lane + 1] && strict_max(yy, lane)) atomicOr(&rowmask[yy], 1ull << lane);
         }
         wave_sync();
         FSTAMP(5);
@@ -899,7 +913,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
         if (!dense)
             for (int e = lane; e < nsq; e += 64) { const int i = queue[e]; emit(i >> 6, i & 63); }
         else
-            for (int i = lane; i < cw * ch; i += 64) { const int yy = i / cw; emit(yy, i - yy * cw); }
+            for (int yy = 0; yy < ch; ++yy) { if (lane < cw) emit(yy, lane); }
     }
     if (lane == 0) cellcnt[(unsigned long long)frame * ncells + c.cell] = (uint16_t)min(total, (int)c.cap);
     FSTAMP(6);
