@@ -1169,13 +1169,17 @@ struct __attribute__((packed, aligned(4))) u96 { uint32_t a, b, c; };
 constexpr int kBlurUnitBytes = 16 * kBlurRows + 16;   // one unit in LDS, padded against bank conflicts
 template <int MODE>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
-                                              unsigned long long blur_bytes, const DevLevel* __restrict__ lv, int nlevels,
-                                              int blocks_per_level, int n_frames)
+                                              unsigned long long blur_bytes, const DevLevel* __restrict__ lv,
+                                              const uint32_t* __restrict__ chunks, int n_frames)
 {
     __shared__ __align__(16) uint8_t s_stage[4][16 * kBlurUnitBytes];
     int frame; uint32_t chunk;
     if (!frame_chunk(n_frames, frame, chunk)) return;
-    const uint32_t level = chunk / (uint32_t)blocks_per_level, blk = chunk - level * (uint32_t)blocks_per_level;
+    // (level << 16 | workgroup inside the level) of every workgroup of a frame: one scalar load, where a division by the
+    // workgroups per level cost every thread some twenty-five vector instructions, and no empty workgroups behind the
+    // small levels
+    const uint32_t entry = chunks[chunk];
+    const uint32_t level = entry >> 16, blk = entry & 0xFFFFu;
     const DevLevel& L = lv[level];
     const uint32_t upr = (uint32_t)L.upr;                              // units (4 threads, 16 pixels) per strip row
     const uint32_t strips = (uint32_t)((L.h + kBlurRows - 1) / kBlurRows);
@@ -1185,9 +1189,10 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t i = blk * 256 + threadIdx.x;                        // thread = (unit i >> 2, quarter i & 3)
     uint8_t* stage = s_stage[wave];
+    uint32_t strip, uc;                                                // of the thread's unit, also for the units past the level
+    split_index(i >> 2, upr, L.upr_magic, strip, uc);
+    const uint32_t my_unit = (strip << 16) | uc;
     if ((i >> 2) < nunits) {
-        uint32_t strip, uc;
-        split_index(i >> 2, upr, L.upr_magic, strip, uc);
         const int y0 = (int)strip * kBlurRows, x = (int)(16 * uc + 4 * (i & 3));
         // wavefront-uniform base (three rows up and four bytes left of the ROI origin) plus a 32-bit lane offset
         const uint32_t stride = (uint32_t)L.stride;
@@ -1256,15 +1261,15 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     for (int s4 = 0; s4 < 4; ++s4) {
         const uint32_t c = 64u * s4 + (uint32_t)lane;
         const uint32_t unit = unit0 + (c >> 4), r = c & 15u;
-        uint32_t strip, uc;
-        split_index(unit, upr, L.upr_magic, strip, uc);
-        const uint32_t y = strip * kBlurRows + r;
+        // (strip, unit in the strip) of unit c >> 4 of the wavefront: lane 4 * (c >> 4) worked them out for its own unit above
+        const uint32_t su = (uint32_t)__shfl((int)my_unit, (int)(4u * (c >> 4)));
+        const uint32_t y = (su >> 16) * kBlurRows + r, ucs = su & 0xFFFFu;
         if (unit < nunits && y < (uint32_t)L.h) {
             const uint4 v = *reinterpret_cast<const uint4*>(stage + ((c >> 4) * kBlurUnitBytes + 16 * r));
             // (nontemporal: nothing reads the blurred levels before k_describe, three kernels on; the pyramid that
             // k_fast_cells is about to read keeps its place in the caches: headline +0.7 %)
             typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(dst + (__umul24(y >> 3, tile_row_bytes) + 128u * uc + 16u * (y & 7u))));
+            __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(dst + (__umul24(y >> 3, tile_row_bytes) + 128u * ucs + 16u * (y & 7u))));
         }
     }
 }
@@ -1809,6 +1814,8 @@ struct orbx_extractor {
     uint8_t* d_pyr = nullptr;
     uint8_t* d_blur = nullptr;   // Gaussian-blurred copy of every level (ROI pixels only), tiled for the descriptor windows
     int max_blur_threads = 0;
+    uint32_t* d_blur_chunks = nullptr;   // (level << 16 | workgroup inside the level) of every workgroup of k_blur for one frame
+    int n_blur_chunks = 0;
     int generic_levels = 0;  // levels produced by k_resize_generic
     uint32_t* d_cand = nullptr;
     uint16_t* d_cellcnt = nullptr;
@@ -2021,7 +2028,7 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
             see(((long)ex->hlv[l].gpr * ((ex->hlv[l].h + kResizeRows - 1) / kResizeRows) + 255) / 256, "resize");
         see((ex->n_small + kFastWavesPerBlock - 1) / kFastWavesPerBlock, "FAST cells");
         see((ex->n_big + kFastWavesPerBlock - 1) / kFastWavesPerBlock, "FAST cells");
-        see((long)((ex->max_blur_threads + 255) / 256) * geo.nlevels, "blur");
+        { long nb = 0; for (int l = 0; l < geo.nlevels; ++l) nb += (ex->hlv[l].upr * ((ex->hlv[l].h + kBlurRows - 1) / kBlurRows) + 63) / 64; see(nb, "blur"); }
         see((geo.kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), "describe");
         if (worst > 65535) {
             set_error(std::string("image too large for this parameter set: the ") + which + " stage needs " + std::to_string(worst) +
@@ -2046,6 +2053,17 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     HIP_CHECK(hipMalloc(&ex->d_nodeof, sizeof(uint16_t) * (size_t)ex->key_total * B));
     HIP_CHECK(hipMalloc(&ex->d_lvlkp, sizeof(uint32_t) * (size_t)geo.kp_total * B));
     HIP_CHECK(hipMalloc(&ex->d_lvlcnt, sizeof(int32_t) * geo.nlevels * B));
+    {
+        std::vector<uint32_t> bc;
+        for (int l = 0; l < geo.nlevels; ++l) {
+            const int units = ex->hlv[l].upr * ((ex->hlv[l].h + kBlurRows - 1) / kBlurRows);
+            for (int b = 0; b < (units + 63) / 64; ++b) bc.push_back(((uint32_t)l << 16) | (uint32_t)b);
+            if ((units + 63) / 64 > 0xFFFF) { set_error("image too large: a level's blur needs more than 65535 workgroups"); return ORBX_ERR_UNSUPPORTED_GEOMETRY; }
+        }
+        ex->n_blur_chunks = (int)bc.size();
+        HIP_CHECK(hipMalloc(&ex->d_blur_chunks, sizeof(uint32_t) * std::max<size_t>(bc.size(), 1)));
+        HIP_CHECK(hipMemcpy(ex->d_blur_chunks, bc.data(), sizeof(uint32_t) * bc.size(), hipMemcpyHostToDevice));
+    }
     for (auto& e : ex->ev) HIP_CHECK(hipEventCreate(&e));
     ex->no_graph = getenv("ORBX_NO_GRAPH") != nullptr;
     guard.e = nullptr;
@@ -2059,7 +2077,7 @@ void orbx_extractor_destroy(orbx_extractor* ex)
     (void)hipSetDevice(ex->device);
     if (ex->stream) (void)hipStreamSynchronize(ex->stream);
     void* ptrs[] = {ex->d_pts, ex->d_octmem, ex->d_lv, ex->d_cells, ex->d_fast_cells, ex->d_rx, ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, ex->d_pyr, ex->d_blur, ex->d_cand, ex->d_cellcnt, ex->d_keys, ex->d_nodeof,
-                    ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount};
+                    ex->d_lvlkp, ex->d_lvlcnt, ex->d_img, ex->d_okp, ex->d_odesc, ex->d_ocount, ex->d_blur_chunks};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     void* hptrs[] = {ex->h_pts, ex->h_img, ex->h_okp, ex->h_odesc, ex->h_ocount, ex->h_level};
     for (void* p : hptrs) if (p) (void)hipHostFree(p);
@@ -2133,12 +2151,11 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     {
         // the blurred levels are only read by k_describe, but the blur runs here, next to the pyramid it reads: with the
         // blur directly in front of it k_describe took 6 % longer (measured, 187 against 176 us per 256 frames)
-        const int bpl = (ex->max_blur_threads + 255) / 256;
-        dim3 gblur(frame_chunk_grid((unsigned)(bpl * G.nlevels), B));
+        dim3 gblur(frame_chunk_grid((unsigned)ex->n_blur_chunks, B));
         if (ex->params.blur_rounding)
-            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels, bpl, B);
+            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, ex->d_blur_chunks, B);
         else
-            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels, bpl, B);
+            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, ex->d_blur_chunks, B);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[2], st));
     {
