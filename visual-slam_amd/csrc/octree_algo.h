@@ -47,14 +47,19 @@ static __device__ __forceinline__ float ot_fdiv(float a, float b) { return __fdi
 // Inclusive prefix sum over the 64 lanes (all active) with DPP adds: shifts by 1, 2, 4, 8 inside each row of 16 lanes (a lane
 // without a source adds 0), then the last lane of row 0 / 2 into row 1 / 3 and lane 31 into rows 2 and 3.  Six dependent
 // vector instructions instead of six LDS round trips through ds_bpermute.
+// (Written as instructions: from the builtin form the compiler makes three per step -- a zero, a DPP move, an add --
+// where one add with a DPP operand does; a lane without a source adds 0 (bound_ctrl), a row outside the row mask keeps
+// its value.  A DPP operand written by the previous vector instruction needs two wait states.)
 static __device__ __forceinline__ int ot_wave_scan_incl(int v)
 {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    asm volatile("s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"     // -> rows 1, 3
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"           // -> rows 2, 3
+                 : "+v"(v));
     return v;
 }
 // base[idx] += 1 for every lane with idx >= 0.  Every lane of the wavefront must call it (idx < 0: nothing to
