@@ -667,7 +667,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
     __shared__ __align__(16) uint8_t s_score[WPB][SR * SS];
     __shared__ unsigned long long s_mask[WPB][MR];
     __shared__ uint16_t s_queue[WPB][QCAP];
-    __shared__ uint16_t s_base[WPB][MR];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything derived from it stays scalar
@@ -685,7 +684,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
     uint8_t* score = s_score[wave];
     unsigned long long* rowmask = s_mask[wave];
     uint16_t* queue = s_queue[wave];
-    uint16_t* rowbase = s_base[wave];
     const int cw = c.cw, ch = c.ch;
     const int tw = cw + 6, th = ch + 6;
     {
@@ -892,28 +890,23 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
         wave_sync();
     }
     // raster-ordered emission: row r's maxima start at the number of maxima in the rows above it (lane r owns row r for
-    // the prefix sum); then every maximum finds its own rank -- its row's start plus the maxima to its left in the
-    // row -- and writes its key: one pass over the corner list instead of one round per maximum of the fullest row
+    // the prefix sum) and follow each other from left to right -- every lane walks the set bits of its own row mask, so
+    // the loop takes as many turns as the fullest row has maxima (two or three), with no pass over the corner list
     const int cnt = __popcll(mask);
     const int inc = ot_wave_scan_incl(cnt);
     const int total = __builtin_amdgcn_readlane(inc, 63);
-    uint32_t* out = cand + (unsigned long long)frame * cand_total + c.out;
     if (total) {
-        if (lane < MR) rowbase[lane] = (uint16_t)(inc - cnt);
-        wave_sync();
-        const uint32_t keybase = ((uint32_t)(3 + c.offx) << 20) | ((uint32_t)(3 + c.offy) << 8);
-        auto emit = [&](int yy, int xx) {
-            const unsigned long long m = rowmask[yy];
-            if ((m >> xx) & 1ull) {
-                const int pos = rowbase[yy] + __popcll(m & ((1ull << xx) - 1ull));
-                const int sc = score[(yy + 1) * SS + xx + 1];
-                if (pos < (int)c.cap) out[pos] = keybase + ((uint32_t)xx << 20) + ((uint32_t)yy << 8) + (uint32_t)sc;
-            }
-        };
-        if (!dense)
-            for (int e = lane; e < nsq; e += 64) { const int i = queue[e]; emit(i >> 6, i & 63); }
-        else
-            for (int yy = 0; yy < ch; ++yy) { if (lane < cw) emit(yy, lane); }
+        uint32_t* out = cand + (unsigned long long)frame * cand_total + c.out;
+        const uint32_t keybase = (((uint32_t)(3 + c.offx) << 20) | ((uint32_t)(3 + c.offy) << 8)) + ((uint32_t)lane << 8);
+        const uint8_t* srow = &score[(lane + 1) * SS + 1];
+        int pos = inc - cnt;
+        unsigned long long m = mask;
+        while (m) {
+            const int xx = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            if (pos < (int)c.cap) out[pos] = keybase + ((uint32_t)xx << 20) + (uint32_t)srow[xx];
+            ++pos;
+        }
     }
     if (lane == 0) cellcnt[(unsigned long long)frame * ncells + c.cell] = (uint16_t)min(total, (int)c.cap);
     FSTAMP(6);
