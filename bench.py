@@ -657,9 +657,8 @@ def worker(a):
                                           "(BASELINE configs[2]; one step = the whole batch)"))
         torch.cuda.empty_cache()
         configs.append(leg_config_extract(cx, vsa, np, "uhd_3840x2160", 3840, 2160, 8000, 12, 128, False, 4, 32, max(2, min(a.steps, 6)), 1,
-                                          "128 HBM-resident 3840x2160 frames per GPU per step (four contexts of 32: a level's quadtree is "
-                                          "one workgroup, so small batches leave most CUs idle during that stage unless other contexts "
-                                          "fill them), nFeatures=8000, 12 levels (BASELINE configs[3])"))
+                                          "128 HBM-resident 3840x2160 frames per GPU per step (four contexts of 32; a single context of 64 "
+                                          "is within 3 % of it), nFeatures=8000, 12 levels (BASELINE configs[3])"))
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ Hamming workload

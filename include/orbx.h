@@ -192,7 +192,9 @@ int orbx_distribute_octree_ex(int device, const uint32_t* packed_keys, int n, in
                               int N, uint32_t* out, int cap, int* n_out, int key_storage);
 
 /* Per-stage device time of the last batch, measured with HIP events on the launch stream when
- * profiling is switched on (no counterpart in the reference).  Stage order: ORBX_STAGE_*. */
+ * profiling is switched on (no counterpart in the reference).  Stage order: ORBX_STAGE_*, which is the order of the
+ * launches: level 0 and the resizes, the Gaussian of every level, the FAST cells, the quadtree selection, orientation +
+ * descriptors (each of the last four is one kernel). */
 enum { ORBX_STAGE_PYRAMID = 0, ORBX_STAGE_BLUR = 1, ORBX_STAGE_FAST = 2, ORBX_STAGE_OCTREE = 3, ORBX_STAGE_DESCRIBE = 4, ORBX_STAGE_COUNT = 5 };
 int orbx_extractor_set_profiling(orbx_extractor* ex, int on);
 int orbx_extractor_stage_ms(orbx_extractor* ex, float* ms /* ORBX_STAGE_COUNT */);
