@@ -242,10 +242,8 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ img,
 // columns 4..1, the three pixels right of it repeat columns w-2..w-4, written as the two dwords that hold them), then
 // 6 * cpr threads copy the three rows above and below the ROI (rows 1..3 and h-2..h-4 with the side pixels they were just
 // given -- by other threads, so those six rows get their side pixels computed here again, not read back).
-__global__ __launch_bounds__(256) void k_level0_frame(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L, int n_frames)
+__device__ __forceinline__ void level0_frame_block(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, const DevLevel& L, int frame, uint32_t blk)
 {
-    int frame; uint32_t blk;
-    if (!frame_chunk(n_frames, frame, blk)) return;
     const uint32_t i = blk * 256 + threadIdx.x;
     uint8_t* roi = pyr + (unsigned long long)frame * pyr_bytes + L.roi;
     const uint32_t nside = (uint32_t)L.h, ncopy = 6u * (uint32_t)L.cpr;
@@ -279,6 +277,13 @@ __global__ __launch_bounds__(256) void k_level0_frame(uint8_t* __restrict__ pyr,
     }
 }
 
+__global__ __launch_bounds__(256) void k_level0_frame(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel L, int n_frames)
+{
+    int frame; uint32_t blk;
+    if (!frame_chunk(n_frames, frame, blk)) return;
+    level0_frame_block(pyr, pyr_bytes, L, frame, blk);
+}
+
 // Level l from level l-1: cv::resize INTER_LINEAR for 8-bit (Q11 weights, two-stage rounding).
 // A thread owns one group of four adjacent destination columns over four consecutive rows, and consecutive
 // lanes own consecutive groups, so each load or store of a wavefront touches a few cache lines.  The four
@@ -306,14 +311,20 @@ __device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b)
     return (uint32_t)(((unsigned long long)(a & 0xFFFFFFu) * (unsigned long long)(b & 0xFFFFFFu)) >> 32);
 }
 
+// frame_blocks: workgroups behind the resize's own that write the REFLECT_101 frame of the source level (level 0 when the
+// frames came by the input view: nothing of the resize reads those pixels -- what its windows touch of them meets a
+// zero weight -- and the blur, which does, runs behind all the resizes; as a launch of its own the three workgroups per
+// frame cost a whole launch latency)
 template <bool kSharedRows>
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned long long pyr_bytes, DevLevel S, DevLevel D,
                                                 const ResizeY* __restrict__ ryt, const ResizeRowBlock* __restrict__ rrb,
-                                                const ResizeGroupA* __restrict__ rga, const ResizeGroupB* __restrict__ rgb, int n_frames)
+                                                const ResizeGroupA* __restrict__ rga, const ResizeGroupB* __restrict__ rgb, int n_frames,
+                                                uint32_t resize_blocks)
 {
     const uint32_t nthreads = (uint32_t)(D.gpr * ((D.h + kResizeRows - 1) / kResizeRows));
     int frame; uint32_t blk;
     if (!frame_chunk(n_frames, frame, blk)) return;
+    if (blk >= resize_blocks) { level0_frame_block(pyr, pyr_bytes, S, frame, blk - resize_blocks); return; }
     const uint32_t i = blk * 256 + threadIdx.x;
     if (i >= nthreads) return;
     uint32_t rb, gx;
@@ -2018,7 +2029,8 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         auto see = [&](long chunks, const char* name) { if (chunks > worst) { worst = chunks; which = name; } };
         see(((long)ex->hlv[0].cpr * ex->hlv[0].h + 255) / 256, "level-0 copy");
         for (int l = 1; l < geo.nlevels; ++l)
-            see(((long)ex->hlv[l].gpr * ((ex->hlv[l].h + kResizeRows - 1) / kResizeRows) + 255) / 256, "resize");
+            see(((long)ex->hlv[l].gpr * ((ex->hlv[l].h + kResizeRows - 1) / kResizeRows) + 255) / 256
+                + (l == 1 ? ((long)ex->hlv[0].h + 6 * ex->hlv[0].cpr + 255) / 256 : 0), "resize");
         see((ex->n_small + kFastWavesPerBlock - 1) / kFastWavesPerBlock, "FAST cells");
         see((ex->n_big + kFastWavesPerBlock - 1) / kFastWavesPerBlock, "FAST cells");
         { long nb = 0; for (int l = 0; l < geo.nlevels; ++l) nb += (ex->hlv[l].upr * ((ex->hlv[l].h + kBlurRows - 1) / kBlurRows) + 63) / 64; see(nb, "blur"); }
@@ -2106,10 +2118,14 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     {
         const DevLevel& L0 = ex->hlv[0];
         dim3 grid(frame_chunk_grid((L0.cpr * L0.h + 255) / 256, B));
+        bool frame_on_resize = false;
         if (ex->channels == 1 && d_images == pyr + L0.roi && row_stride == (ptrdiff_t)L0.stride && frame_stride == (ptrdiff_t)G.pyr_bytes) {
-            // the frames already lie where level 0 lives (orbx_extractor_input_view): no copy, only the REFLECT_101 frame
-            hipLaunchKernelGGL(k_level0_frame, frame_chunk_grid((unsigned)((L0.h + 6 * L0.cpr + 255) / 256), B), dim3(256), 0, st, pyr,
-                               (unsigned long long)G.pyr_bytes, L0, B);
+            // the frames already lie where level 0 lives (orbx_extractor_input_view): no copy, only the REFLECT_101 frame,
+            // which rides on the launch of level 1 when that is the fast resize kernel
+            if (G.nlevels >= 2 && ex->hlv[1].fast_resize) frame_on_resize = true;
+            else
+                hipLaunchKernelGGL(k_level0_frame, frame_chunk_grid((unsigned)((L0.h + 6 * L0.cpr + 255) / 256), B), dim3(256), 0, st, pyr,
+                                   (unsigned long long)G.pyr_bytes, L0, B);
         } else if (ex->channels == 1)
             hipLaunchKernelGGL(k_level0, grid, dim3(256), 0, st, d_images, (long long)row_stride, (long long)frame_stride,
                                pyr, (unsigned long long)G.pyr_bytes, L0, B);
@@ -2122,13 +2138,15 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
         for (int l = 1; l < G.nlevels; ++l) {
             const DevLevel& D = ex->hlv[l];
             if (D.fast_resize) {
-                dim3 g2(frame_chunk_grid((D.gpr * ((D.h + kResizeRows - 1) / kResizeRows) + 255) / 256, B));
+                const unsigned rblocks = (unsigned)((D.gpr * ((D.h + kResizeRows - 1) / kResizeRows) + 255) / 256);
+                const unsigned fblocks = l == 1 && frame_on_resize ? (unsigned)((L0.h + 6 * L0.cpr + 255) / 256) : 0u;
+                dim3 g2(frame_chunk_grid(rblocks + fblocks, B));
                 if (D.fast_resize == 2)
                     hipLaunchKernelGGL(k_resize<true>, g2, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
-                                       ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, B);
+                                       ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, B, rblocks);
                 else
                     hipLaunchKernelGGL(k_resize<false>, g2, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
-                                       ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, B);
+                                       ex->d_ry, ex->d_rrb, ex->d_rga, ex->d_rgb, B, rblocks);
             } else {
                 dim3 g2((D.w + 255) / 256, (D.h + 3) / 4, B);
                 hipLaunchKernelGGL(k_resize_generic, g2, dim3(256), 0, st, pyr, (unsigned long long)G.pyr_bytes, ex->hlv[l - 1], D,
