@@ -20,6 +20,16 @@ def test_library_exports_every_declared_symbol(vsa):
     assert set(vsa.EXPORTED) <= declared
 
 
+def test_stage_names_follow_the_header(vsa):
+    """orbx_extractor_stage_ms fills ORBX_STAGE_COUNT floats in the order of the ORBX_STAGE_* enumerators: the Python view's
+    stage names (and with them bench.py's per-stage accounting) must be that list."""
+    header = open(os.path.join(ROOT, "include", "orbx.h")).read()
+    enum = dict((name.lower(), int(value)) for name, value in re.findall(r"ORBX_STAGE_([A-Z]+) = (\d+)", header))
+    count = enum.pop("count")
+    assert count == len(vsa.STAGES) == len(enum)
+    assert [name for name, _ in sorted(enum.items(), key=lambda kv: kv[1])] == list(vsa.STAGES)
+
+
 def test_tables_match_oracle(vsa, oracle):
     for nf, sf, nl in ((1000, 1.2, 8), (2000, 1.2, 8), (1200, 1.2, 8), (8000, 1.2, 12), (500, 1.3, 5), (1000, 2.0, 3)):
         a = vsa.scale_tables(vsa.make_params(nf, sf, nl))
