@@ -36,9 +36,9 @@ for k, d in mean.items():
     if "SQ_INSTS_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
         kern[k]["valu_issue_frac"] = round(d["SQ_INSTS_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 3)
 tot = lambda k, n=1: n * (kern.get(k, {}).get("read_bytes", 0) + kern.get(k, {}).get("write_bytes", 0))
-# level 0: the batches of the timed region read their frames from the input view, where only the frame kernel runs (the copy kernel
-# appears in the passes once, when the view is filled)
-level0 = tot("k_level0_frame") if "k_level0_frame" in kern else tot("k_level0")
+# level 0: the batches of the timed region read their frames from the input view, where no kernel of its own runs (the frame of
+# level 0 is written inside the first resize launch; the copy kernel appears in the passes once, when the view is filled)
+level0 = tot("k_level0_frame")
 stages = {"pyramid": level0 + tot("k_resize", resizes) + tot("k_borders"), "fast": tot("k_fast_cells"),
           "octree": tot("k_octree"), "blur": tot("k_blur"), "describe": tot("k_describe")}
 json.dump({"build_stamp": stamp, "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_WRITE_DRAM_32B_sum over "
