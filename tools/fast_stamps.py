@@ -29,4 +29,4 @@ for it in range(3):
     lib.orbx_debug_fast_stamps(out)
     n = out[15]
     tot = sum(out[i] for i in range(len(names)))
-    print(f"cells {n}: " + ", ".join(f"{nm} {out[i] / n:.0f} ({100 * out[i] / tot:.0f}%)" for i, nm in enumerate(names)) + f" | total {tot / n:.0f} cycles per cell")
+    print(f"cells {n}: " + ", ".join(f"{nm} {out[i] / n:.2f} ({100 * out[i] / tot:.0f}%)" for i, nm in enumerate(names)) + f" | total {tot / n:.0f} cycles per cell")

@@ -392,9 +392,15 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
             const us16x2 w = __builtin_bit_cast(us16x2, wt[k]);
             const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r0[r].y, r0[r].x, sel[k])), w, 0u, false);
             const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(r1[r].y, r1[r].x, sel[k])), w, 0u, false);
-            b[k] = (mul_hi_u24(c0, h0 & ~15u) + mul_hi_u24(c1, h1 & ~15u) + 2u) >> 2;
+            b[k] = mul_hi_u24(c0, h0 & ~15u) + mul_hi_u24(c1, h1 & ~15u) + 2u;             // <= 1026: four times the pixel
         }
-        out[r] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(b[3], b[2], 0x0c0c0400u), __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u), 0x05040100u);
+        // >> 2 on two sums at a time (16 bits apart: what the shift moves from the upper sum into the lower half lands
+        // above the byte that is kept), then one byte select
+        // (the pairing as an instruction: the compiler otherwise folds the + 2 of the upper sum into a constant of its own)
+        uint32_t u01, u23;
+        asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(u01) : "v"(b[1]), "v"(b[0]));
+        asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(u23) : "v"(b[3]), "v"(b[2]));
+        out[r] = __builtin_amdgcn_perm(u23 >> 2, u01 >> 2, 0x06040200u);
     }
 #pragma unroll
     for (int r = 0; r < kResizeRows; ++r) {
@@ -513,6 +519,8 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // needs fewer operations but more issue time here)
 __device__ __forceinline__ int min3_op(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ int max3_op(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int min2_op(int a, int b) { int r; asm("v_min_i32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ int max2_op(int a, int b) { int r; asm("v_max_i32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ int min16i(const int (&m)[16])
 {
     // three partial chains, so that consecutive instructions do not wait for each other
@@ -563,14 +571,21 @@ __device__ __forceinline__ int fast_side(const uint8_t* t)
     const int v = t[0];
     const int p[16] = {t[3 * TS], t[3 * TS + 1], t[2 * TS + 2], t[TS + 3], t[3], t[-TS + 3], t[-2 * TS + 2], t[-3 * TS + 1],
                        t[-3 * TS], t[-3 * TS - 1], t[-2 * TS - 2], t[-TS - 3], t[-3], t[TS - 3], t[2 * TS - 2], t[3 * TS - 1]};
-    int e3[16], arc[16];
+    int e3[16], two[8];
 #pragma unroll
     for (int k = 0; k < 16; ++k)
         e3[k] = DARK ? max3_op(p[k], p[(k + 1) & 15], p[(k + 2) & 15]) : min3_op(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+    // The arc k..k+8 is e3[k], e3[k+3], e3[k+6].  Arcs k and k+3 share two of the three, and
+    // min(max(a,b,c), max(b,c,d)) = max(b, c, min(a,d)): two arcs cost two operations and leave one value, and the sixteen
+    // arcs fall into the eight pairs (k, k+3), k = 0, 6, 12, 2, 8, 14, 4, 10 (mod 16).
 #pragma unroll
-    for (int k = 0; k < 16; ++k)                                                   // ring k..k+8
-        arc[k] = DARK ? max3_op(e3[k], e3[(k + 3) & 15], e3[(k + 6) & 15]) : min3_op(e3[k], e3[(k + 3) & 15], e3[(k + 6) & 15]);
-    return DARK ? v - min16i(arc) : max16i(arc) - v;
+    for (int i = 0; i < 8; ++i) {
+        const int k = (6 * i) & 15;
+        const int a = e3[k], b = e3[(k + 3) & 15], c = e3[(k + 6) & 15], d = e3[(k + 9) & 15];
+        two[i] = DARK ? max3_op(b, c, min2_op(a, d)) : min3_op(b, c, max2_op(a, d));
+    }
+    if constexpr (DARK) return v - min2_op(min3_op(min3_op(two[0], two[1], two[2]), min3_op(two[3], two[4], two[5]), two[6]), two[7]);
+    else return max2_op(max3_op(max3_op(two[0], two[1], two[2]), max3_op(two[3], two[4], two[5]), two[6]), two[7]) - v;
 }
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -702,7 +717,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
         // is issued before the first store and the addresses are a uniform base plus a 32-bit lane offset (left to itself
         // the compiler unrolls the loop eightfold around 64-bit multiply-adds)
         constexpr int LPR = TS / 16, RPI = 64 / LPR, NIT = (TR + RPI - 1) / RPI;
-        const int r0 = (int)(__umul24((uint32_t)lane, (256u + LPR - 1) / LPR) >> 8), j = lane - (LPR == 3 ? r0 + (r0 << 1) : r0 + (r0 << 2));   // lane / LPR (exact for lane < 64, LPR 3 or 5)
+        const int r0 = (int)(__umul24((uint32_t)lane, (256u + LPR - 1) / LPR) >> 8);   // lane / LPR (exact for lane < 64, LPR 3 or 5)
+        int j;                                                   // lane % LPR (as an instruction: the compiler picks the 64-bit multiply-add)
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(j) : "v"(r0), "n"(-LPR), "v"(lane));
         static_assert(LPR == 3 || LPR == 5, "the reciprocal above is checked for these");
         const bool act = lane < LPR * RPI && 16 * j < tw;
         const uint32_t goff = __umul24((uint32_t)r0, c.stride) + 16u * (uint32_t)j, gstep0 = (uint32_t)RPI * c.stride;
@@ -765,9 +782,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
                 const int val = fast_side<TS, DARK>(&tile[(yy + 3) * TS + xx + 3]);
                 keep = val > T;
                 if (keep) {
-                    uint8_t* sp = &score[(yy + 1) * SS + xx + 1];
-                    // a pixel that survived on both sides may already hold its dark score
-                    *sp = (uint8_t)(DARK ? val - 1 : max((int)*sp, val - 1));
+                    // (a pixel queued on both sides is a corner on one at most: two arcs of nine do not fit the ring of sixteen)
+                    score[(yy + 1) * SS + xx + 1] = (uint8_t)(val - 1);
                 }
             }
             const unsigned long long m = __ballot(keep);
