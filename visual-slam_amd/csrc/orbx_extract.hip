@@ -565,12 +565,15 @@ __device__ __forceinline__ int fast_score(const uint8_t* t)
 // minimum); the pixel is a corner on that side at threshold T iff the value exceeds T, and its score is then the larger
 // side's value - 1.  A survivor of the pretest on one side only cannot be a corner on the other side (the other side's
 // value is at most its pretest margin, which did not exceed T), so a corner found on one side alone has that side's score.
+// flip: 0, or 0xFF for a lane that wants the bright side from the DARK form -- with every pixel complemented, B - v of the
+// pixels is v' - A' of the complements (a wavefront whose lanes differ in side pays seventeen exclusive-ors, not two passes).
 template <int TS, bool DARK>
-__device__ __forceinline__ int fast_side(const uint8_t* t)
+__device__ __forceinline__ int fast_side(const uint8_t* t, const int flip = 0)
 {
-    const int v = t[0];
-    const int p[16] = {t[3 * TS], t[3 * TS + 1], t[2 * TS + 2], t[TS + 3], t[3], t[-TS + 3], t[-2 * TS + 2], t[-3 * TS + 1],
-                       t[-3 * TS], t[-3 * TS - 1], t[-2 * TS - 2], t[-TS - 3], t[-3], t[TS - 3], t[2 * TS - 2], t[3 * TS - 1]};
+    const int v = t[0] ^ flip;
+    const int p[16] = {t[3 * TS] ^ flip, t[3 * TS + 1] ^ flip, t[2 * TS + 2] ^ flip, t[TS + 3] ^ flip, t[3] ^ flip, t[-TS + 3] ^ flip,
+                       t[-2 * TS + 2] ^ flip, t[-3 * TS + 1] ^ flip, t[-3 * TS] ^ flip, t[-3 * TS - 1] ^ flip, t[-2 * TS - 2] ^ flip,
+                       t[-TS - 3] ^ flip, t[-3] ^ flip, t[TS - 3] ^ flip, t[2 * TS - 2] ^ flip, t[3 * TS - 1] ^ flip};
     int e3[16], two[8];
 #pragma unroll
     for (int k = 0; k < 16; ++k)
@@ -766,28 +769,33 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
             }
         }
     };
-    // one side's exact value of queue[first .. first + n): corners (value > T) go to the score tile with score value - 1
-    // and are compacted to queue[dst ..), dst <= first (a scored entry is written at or below the slot its lane just
-    // read, so no waiting entry is overwritten); returns their number
-    auto score_side = [&](auto dark, int first, int n, int T, int dst) -> int {
-        constexpr bool DARK = decltype(dark)::value;
+    // exact value of the queued survivors, dark list queue[0 .. nd) and bright list queue[nd .. nd + nb), each on its own
+    // side: corners (value > T) go to the score tile with score value - 1 and are compacted to queue[0 ..) (a scored entry
+    // is written at or below the slot its lane just read, so no waiting entry is overwritten); returns their number.
+    // The two lists are walked as one, 64 entries a turn, so that only one turn is partly filled; the turn that holds
+    // the end of the dark list and the start of the bright one takes the dark form with the bright lanes' pixels
+    // complemented.
+    auto score_lists = [&](int nd, int nb, int T) -> int {
+        const int n = nd + nb;
         int kept = 0;
         for (int e0 = 0; e0 < n; e0 += 64) {
             const int e = e0 + lane;
             bool keep = false;
             int i = 0;
             if (e < n) {
-                i = queue[first + e];
+                i = queue[e];
                 const int yy = i >> 6, xx = i & 63;
-                const int val = fast_side<TS, DARK>(&tile[(yy + 3) * TS + xx + 3]);
+                const uint8_t* t = &tile[(yy + 3) * TS + xx + 3];
+                int val;
+                if (min(e0 + 64, n) <= nd) val = fast_side<TS, true>(t);
+                else if (e0 >= nd) val = fast_side<TS, false>(t);
+                else val = fast_side<TS, true>(t, e >= nd ? 0xFF : 0);
                 keep = val > T;
-                if (keep) {
-                    // (a pixel queued on both sides is a corner on one at most: two arcs of nine do not fit the ring of sixteen)
-                    score[(yy + 1) * SS + xx + 1] = (uint8_t)(val - 1);
-                }
+                // (a pixel queued on both sides is a corner on one at most: two arcs of nine do not fit the ring of sixteen)
+                if (keep) score[(yy + 1) * SS + xx + 1] = (uint8_t)(val - 1);
             }
             const unsigned long long m = __ballot(keep);
-            if (keep) queue[dst + kept + lanes_below(m)] = (uint16_t)i;
+            if (keep) queue[kept + lanes_below(m)] = (uint16_t)i;
             kept += __popcll(m);
         }
         return kept;
@@ -877,10 +885,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(TR <= 
             enqueue(bbits, nd + (incl >> 16) - mine_b);
             wave_sync();
             FSTAMP(3);
-            // pass 2: exact value of the queued survivors, one side per list; the corners end up in queue[0..nsq)
-            const int kd = score_side(std::true_type{}, 0, nd, T, 0);
-            wave_sync();
-            nsq = kd + score_side(std::false_type{}, nd, nb, T, kd);
+            // pass 2: exact value of the queued survivors, each on its list's side; the corners end up in queue[0..nsq)
+            nsq = score_lists(nd, nb, T);
             wave_sync();
             FSTAMP(4);
             // pass 3: strict local maxima inside the cell among the corners, one lane per corner; row masks of the maxima
