@@ -1481,11 +1481,20 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
                                                   int32_t* __restrict__ ocount, int cap_per_frame, int n_frames, int trig_mode)
 {
     __shared__ __align__(16) uint4 s_win[4][kBlurW * kWinChunks + 1];
+    __shared__ __align__(16) float4 s_pat[256];
+    __shared__ __align__(16) uint32_t s_ic[256];
+    static_assert(sizeof(PatternF) == 256 * sizeof(float4) && sizeof(IcTable) == 256 * sizeof(uint32_t), "one entry per thread");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // slot arithmetic stays scalar
     int frame; uint32_t chunk;
-    if (!frame_chunk(n_frames, frame, chunk)) return;
+    if (!frame_chunk(n_frames, frame, chunk)) return;                    // (the same for the whole workgroup)
+    // The lane constants of every wavefront -- 4 KB of pattern points, 1 KB of disc weights -- come in once per workgroup
+    // and reach the four wavefronts through LDS: fetched per wavefront they were a quarter of the kernel's requests to
+    // the address unit, which is what bounds it.
+    s_pat[threadIdx.x] = reinterpret_cast<const float4*>(c_pattern_f.v)[threadIdx.x];
+    s_ic[threadIdx.x] = reinterpret_cast<const uint32_t*>(&c_ic)[threadIdx.x];
+    __syncthreads();
     const int slot0 = ((int)chunk * 4 + wave) * kKpPerWave;
     if (slot0 >= kp_total) return;
     uint4* win = s_win[wave];
@@ -1500,14 +1509,16 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     const int crow = min(lane >> 1, kPatch - 1), chalf = lane & 1;
     const int cv = crow - kHalfPatch;
     uint32_t cwu[4], cwm[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        cwu[k] = disc_lane ? c_ic.wu[cv < 0 ? -cv : cv][4 * chalf + k] : 0u;
-        cwm[k] = disc_lane ? c_ic.wm[cv < 0 ? -cv : cv][4 * chalf + k] : 0u;
+    {
+        const int av = cv < 0 ? -cv : cv;
+        const uint4 wu4 = reinterpret_cast<const uint4*>(s_ic)[2 * av + chalf];            // IcTable::wu[av][4 * chalf ..]
+        const uint4 wm4 = reinterpret_cast<const uint4*>(s_ic)[32 + 2 * av + chalf];       // IcTable::wm[av][4 * chalf ..]
+        cwu[0] = disc_lane ? wu4.x : 0u; cwu[1] = disc_lane ? wu4.y : 0u; cwu[2] = disc_lane ? wu4.z : 0u; cwu[3] = disc_lane ? wu4.w : 0u;
+        cwm[0] = disc_lane ? wm4.x : 0u; cwm[1] = disc_lane ? wm4.y : 0u; cwm[2] = disc_lane ? wm4.z : 0u; cwm[3] = disc_lane ? wm4.w : 0u;
     }
     float4 pat[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pat[g] = reinterpret_cast<const float4*>(c_pattern_f.v)[g * 64 + lane];
+    for (int g = 0; g < 4; ++g) pat[g] = s_pat[g * 64 + lane];
 
     // (level, index, output row) of the wave's slots and their keys, all scalar
     int jlevel[kKpPerWave], jidx[kKpPerWave], jout[kKpPerWave];
