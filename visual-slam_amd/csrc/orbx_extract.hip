@@ -1483,6 +1483,11 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     __shared__ __align__(16) uint4 s_win[4][kBlurW * kWinChunks + 1];
     __shared__ __align__(16) float4 s_pat[256];
     __shared__ __align__(16) uint32_t s_ic[256];
+    // results of a wavefront's four keypoints, stored together at the end: 4 x 32 descriptor bytes, 4 x 7 record words
+    // (eight apart), 4 output rows (-1: slot not in use)
+    __shared__ __align__(16) unsigned long long s_desc[4][4 * 4];
+    __shared__ __align__(16) uint32_t s_rec[4][4 * 8];
+    __shared__ __align__(16) int32_t s_row[4][4];
     static_assert(sizeof(PatternF) == 256 * sizeof(float4) && sizeof(IcTable) == 256 * sizeof(uint32_t), "one entry per thread");
 
     const int lane = threadIdx.x & 63;
@@ -1536,6 +1541,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         total += cnt;
     }
     if (slot0 == 0 && lane == 0) ocount[frame] = total;
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kKpPerWave; ++q) s_row[wave][q] = jlevel[q] >= 0 ? jout[q] : -1;
+    }
     uint32_t jkey[kKpPerWave];
 #pragma unroll
     for (int q = 0; q < kKpPerWave; ++q)
@@ -1634,8 +1643,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_a), q));
         const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_b), q));
         const int wshift = (kx - 18) & 15;
-        const size_t orow = (size_t)frame * cap_per_frame + jout[q];
-        unsigned long long* dout = reinterpret_cast<unsigned long long*>(odesc + orow * 32);
         wave_sync();
         // cvRound by adding 1.5 * 2^23: the low bits of the sum's encoding are the rounded integer (ties to even)
         constexpr float kMagic = 12582912.f;
@@ -1650,24 +1657,35 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             const int t0 = wb[(int)(18 + r0) * (16 * kWinChunks) + (int)(18 + c0) + wshift];
             const int t1 = wb[(int)(18 + r1) * (16 * kWinChunks) + (int)(18 + c1) + wshift];
             const unsigned long long bits = __ballot(t0 < t1);
-            if (lane == 0) dout[g] = bits;
+            if (lane == 0) s_desc[wave][4 * q + g] = bits;
         }
         if (lane == 0) {
-            orbx_keypoint kp;
-            kp.x = (float)kx; kp.y = (float)ky;
-            if (level != 0) { kp.x = __fmul_rn(kp.x, L.scale); kp.y = __fmul_rn(kp.y, L.scale); }
-            kp.size = L.kp_size;
-            kp.angle = angle;
-            kp.response = (float)resp;
-            kp.octave = level;
-            kp.class_id = -1;
-            okp[orow] = kp;
+            float x = (float)kx, y = (float)ky;
+            if (level != 0) { x = __fmul_rn(x, L.scale); y = __fmul_rn(y, L.scale); }
+            // orbx_keypoint: x, y, size, angle, response, octave, class_id
+            uint4* rec = reinterpret_cast<uint4*>(&s_rec[wave][8 * q]);
+            rec[0] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(L.kp_size), __float_as_uint(angle));
+            rec[1] = make_uint4(__float_as_uint((float)resp), (uint32_t)level, 0xFFFFFFFFu, 0u);
         }
     };
     stage(0, fa); fetch_window(2, fa); process(0);
     stage(1, fb); fetch_window(3, fb); process(1);
     stage(2, fa); process(2);
     stage(3, fb); process(3);
+    // One store instruction for the four descriptors (lane 4q + g: the g-th eight bytes of keypoint q) and one for the four
+    // records (lane 7q + f: word f of keypoint q), instead of six single-lane stores per keypoint -- those were a seventh
+    // of the kernel's time.  Consecutive slots mostly have consecutive output rows, so the lanes' addresses adjoin.
+    static_assert(sizeof(orbx_keypoint) == 28, "seven words per record");
+    wave_sync();
+    if (lane < 4 * kKpPerWave) {
+        const int row = s_row[wave][lane >> 2];
+        if (row >= 0) reinterpret_cast<unsigned long long*>(odesc + ((size_t)frame * cap_per_frame + row) * 32)[lane & 3] = s_desc[wave][lane];
+    }
+    if (lane < 7 * kKpPerWave) {
+        const int q = (lane * 37) >> 8, f = lane - 7 * q;                  // lane / 7 for lane < 28
+        const int row = s_row[wave][q];
+        if (row >= 0) reinterpret_cast<uint32_t*>(okp + ((size_t)frame * cap_per_frame + row))[f] = s_rec[wave][8 * q + f];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
