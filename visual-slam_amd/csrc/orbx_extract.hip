@@ -1470,7 +1470,7 @@ constexpr PatternF make_pattern_f()
 __device__ __constant__ __align__(16) PatternF c_pattern_f = make_pattern_f();
 
 // A wavefront describes kKpPerWave consecutive keypoint slots one after the other, so that what depends only on
-// the lane (disc weights, pattern points, load offsets in units of rows and bytes) is set up once.
+// the lane (disc weights, load offsets in units of rows and bytes) is set up once.
 constexpr int kKpPerWave = 4;
 
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
@@ -1521,9 +1521,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         cwu[0] = disc_lane ? wu4.x : 0u; cwu[1] = disc_lane ? wu4.y : 0u; cwu[2] = disc_lane ? wu4.z : 0u; cwu[3] = disc_lane ? wu4.w : 0u;
         cwm[0] = disc_lane ? wm4.x : 0u; cwm[1] = disc_lane ? wm4.y : 0u; cwm[2] = disc_lane ? wm4.z : 0u; cwm[3] = disc_lane ? wm4.w : 0u;
     }
-    float4 pat[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) pat[g] = s_pat[g * 64 + lane];
 
     // (level, index, output row) of the wave's slots and their keys, all scalar
     int jlevel[kKpPerWave], jidx[kKpPerWave], jout[kKpPerWave];
@@ -1649,7 +1646,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         constexpr uint32_t kBias = 0x4B400000u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 pt = pat[g];
+            // (read where it is used: held in registers for the whole kernel the 256 pairs cost sixteen of them and the
+            // eighth wavefront per SIMD)
+            const float4 pt = s_pat[g * 64 + lane];
             const uint32_t r0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)), kMagic)) - kBias;
             const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)), kMagic)) - kBias;
             const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)), kMagic)) - kBias;
