@@ -1688,11 +1688,14 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
 }
 
 // ---------------------------------------------------------------------------------------------
-// Frame::ComputeStereoMatches, sub-pixel part (src/Frame.cc:551-623): one wavefront per left keypoint whose Hamming
-// match is below (TH_HIGH + TH_LOW) / 2.  11x11 windows of the two extractors' pyramids at the keypoint's level,
-// SAD (L1 norm of the centre-subtracted windows: integer-valued, so exact in integers) for the 11 column shifts,
-// parabola fit and disparity test in float exactly as written in the reference.
+// Frame::ComputeStereoMatches, sub-pixel part (src/Frame.cc:551-623).  A wavefront takes kRefineGroup consecutive left
+// keypoints: a lane each reads its keypoint's match and decides whether it is refined at all (Hamming distance below
+// (TH_HIGH + TH_LOW) / 2: about a tenth of them), then the wavefront works through the ones that are, one after the
+// other with all its lanes -- 11x11 windows of the two extractors' pyramids at the keypoint's level, SAD (L1 norm of the
+// centre-subtracted windows: integer-valued, so exact in integers) for the 11 column shifts, parabola fit and disparity
+// test in float exactly as written in the reference -- and every lane stores its own keypoint's result.
 // ---------------------------------------------------------------------------------------------
+constexpr int kRefineGroup = 16;
 __global__ __launch_bounds__(256) void k_stereo_refine(const uint8_t* __restrict__ pyrL, const uint8_t* __restrict__ pyrR,
                                                        unsigned long long pyr_bytes, const DevLevel* __restrict__ lv, int nlevels,
                                                        const orbx_keypoint* __restrict__ kl, const int32_t* __restrict__ nl_arr,
@@ -1704,80 +1707,129 @@ __global__ __launch_bounds__(256) void k_stereo_refine(const uint8_t* __restrict
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = blockIdx.y;
-    const int iL = blockIdx.x * 4 + wave;
-    if (iL >= min(nl_arr[pair], cap)) return;
-    const size_t row = (size_t)pair * cap + iL;
-    float out_u = -1.0f, out_d = -1.0f;
-    int out_s = -1;
-    const int bd = best_dist[row];
+    const int i0 = (blockIdx.x * 4 + wave) * kRefineGroup;
+    const int nl = min(nl_arr[pair], cap);
+    if (i0 >= nl) return;
+    constexpr int w = 5, R = 5;
     constexpr int thOrbDist = (100 + 50) / 2;
-    const orbx_keypoint k = kl[row];
-    if (bd >= 0 && bd < thOrbDist && k.octave >= 0 && k.octave < nlevels) {
-        const DevLevel& L = lv[k.octave];
-        const float uR0 = kr[(size_t)pair * cap + best_idx[row]].x;
-        const float sf = L.inv_scale;
-        const float scaleduL = roundf(__fmul_rn(k.x, sf)), scaledvL = roundf(__fmul_rn(k.y, sf)), scaleduR0 = roundf(__fmul_rn(uR0, sf));
-        constexpr int w = 5, R = 5;
-        const float iniu = scaleduR0 + (float)(R - w), endu = scaleduR0 + (float)(R + w + 1);
-        const int yl = (int)scaledvL, xl = (int)scaleduL, xr = (int)scaleduR0;
-        // rowRange/colRange outside the level throw in OpenCV (keypoints lie at least 19 pixels inside their level, so
-        // this does not happen on extractor output); such a keypoint gets no match here
-        const bool inside = yl - w >= 0 && yl + w < L.h && xl - w >= 0 && xl + w < L.w && xr - R - w >= 0;
-        if (!(iniu < 0.f || endu >= (float)L.w) && inside) {
-            const uint8_t* imL = pyrL + (unsigned long long)pair * pyr_bytes + L.roi;
-            const uint8_t* imR = pyrR + (unsigned long long)pair * pyr_bytes + L.roi;
-            const int cL = imL[(long long)yl * L.stride + xl];
-            int cR[2 * R + 1], acc[2 * R + 1];
-#pragma unroll
-            for (int i = 0; i <= 2 * R; ++i) { cR[i] = imR[(long long)yl * L.stride + xr + i - R]; acc[i] = 0; }
-            for (int pos = lane; pos < (2 * w + 1) * (2 * w + 1); pos += 64) {
-                const int dy = pos / (2 * w + 1) - w, dx = pos - (dy + w) * (2 * w + 1) - w;
-                const int a = (int)imL[(long long)(yl + dy) * L.stride + xl + dx] - cL;
-                const uint8_t* rr = imR + (long long)(yl + dy) * L.stride + xr + dx - R;
-#pragma unroll
-                for (int i = 0; i <= 2 * R; ++i) { const int b = (int)rr[i] - cR[i]; acc[i] += abs(a - b); }
-            }
-#pragma unroll
-            for (int i = 0; i <= 2 * R; ++i)
-                acc[i] = wave_sum_i32(acc[i]);
-            int bestDist = 2147483647, bestinc = 0;
-#pragma unroll
-            for (int i = 0; i <= 2 * R; ++i) if (acc[i] < bestDist) { bestDist = acc[i]; bestinc = i - R; }
-            if (bestinc != -R && bestinc != R) {
-                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll
-                for (int i = 1; i < 2 * R; ++i) if (i - R == bestinc) { d1 = (float)acc[i - 1]; d2 = (float)acc[i]; d3 = (float)acc[i + 1]; }
-                const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
-                if (!(deltaR < -1.f || deltaR > 1.f)) {
-                    float bestuR = __fmul_rn(L.scale, __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
-                    float disparity = __fsub_rn(k.x, bestuR);
-                    if (disparity >= min_d && disparity < max_d) {
-                        if (disparity <= 0.f) { disparity = 0.01f; bestuR = (float)((double)k.x - 0.01); }
-                        out_d = __fdiv_rn(bf, disparity);
-                        out_u = bestuR;
-                        out_s = bestDist;
-                    }
+    // every lane: what its own keypoint needs (the part of :551-585 that involves no pixels).  Keypoints whose windows
+    // would leave the level get no match (rowRange/colRange outside the level throw in OpenCV; keypoints lie at least 19
+    // pixels inside their level, so this does not happen on extractor output).
+    const bool mine = lane < kRefineGroup && i0 + lane < nl;
+    const size_t row = (size_t)pair * cap + i0 + (mine ? lane : 0);
+    float kx = 0.f, lscale = 0.f, scaleduR0 = 0.f;
+    uint32_t offL = 0, offR = 0, stride = 0;                 // of the window centres inside a frame's pyramid; bytes per row
+    bool cand = false;
+    if (mine) {
+        const int bd = best_dist[row];
+        if (bd >= 0 && bd < thOrbDist) {
+            const orbx_keypoint k = kl[row];
+            if (k.octave >= 0 && k.octave < nlevels) {
+                const DevLevel& L = lv[k.octave];
+                const float uR0 = kr[(size_t)pair * cap + best_idx[row]].x;
+                const float sf = L.inv_scale;
+                const float scaleduL = roundf(__fmul_rn(k.x, sf)), scaledvL = roundf(__fmul_rn(k.y, sf));
+                scaleduR0 = roundf(__fmul_rn(uR0, sf));
+                const float iniu = scaleduR0 + (float)(R - w), endu = scaleduR0 + (float)(R + w + 1);
+                const int yl = (int)scaledvL, xl = (int)scaleduL, xr = (int)scaleduR0;
+                const bool inside = yl - w >= 0 && yl + w < L.h && xl - w >= 0 && xl + w < L.w && xr - R - w >= 0;
+                if (!(iniu < 0.f || endu >= (float)L.w) && inside) {
+                    cand = true;
+                    kx = k.x; lscale = L.scale; stride = (uint32_t)L.stride;
+                    offL = (uint32_t)L.roi + (uint32_t)yl * stride + (uint32_t)xl;
+                    offR = (uint32_t)L.roi + (uint32_t)yl * stride + (uint32_t)xr;
                 }
             }
         }
     }
-    if (lane == 0) { uright[row] = out_u; depth[row] = out_d; sad[row] = out_s; }
+    // window position of the lane in the two passes over the 121 pixels (pass 1: 57 lanes)
+    const int dy0 = (lane * 373 >> 12) - w, dx0 = lane - (dy0 + w) * (2 * w + 1) - w;               // lane / 11 for lane < 128
+    const int pos1 = lane + 64;
+    const int dy1 = (pos1 * 373 >> 12) - w, dx1 = pos1 - (dy1 + w) * (2 * w + 1) - w;
+    const bool in1 = pos1 < (2 * w + 1) * (2 * w + 1);
+    const uint8_t* imL = pyrL + (unsigned long long)pair * pyr_bytes;
+    const uint8_t* imR = pyrR + (unsigned long long)pair * pyr_bytes;
+    // the wavefront works through its candidates: SAD of the centre-subtracted 11x11 windows for the 11 shifts,
+    // |(l - cL) - (r_i - cR_i)| = |(l - r_i) - (cL - cR_i)| with the centre pair taken from the lane that holds it (pass 0,
+    // lane 60), so that one round of loads serves a keypoint
+    int r_best = -1, r_inc = 0, r_prev = 0, r_next = 0;
+    unsigned long long todo = __ballot(cand);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t oL = (uint32_t)__builtin_amdgcn_readlane((int)offL, src), oR = (uint32_t)__builtin_amdgcn_readlane((int)offR, src);
+        const int st = __builtin_amdgcn_readlane((int)stride, src);
+        const uint8_t* pl0 = imL + oL + (dy0 * st + dx0);
+        const uint8_t* pr0 = imR + oR + (dy0 * st + dx0 - R);
+        const uint8_t* pl1 = imL + oL + (in1 ? dy1 * st + dx1 : 0);
+        const uint8_t* pr1 = imR + oR + (in1 ? dy1 * st + dx1 - R : -R);
+        const int l0 = pl0[0], l1 = pl1[0];
+        int t0[2 * R + 1], t1[2 * R + 1];
+#pragma unroll
+        for (int i = 0; i <= 2 * R; ++i) { t0[i] = l0 - (int)pr0[i]; t1[i] = l1 - (int)pr1[i]; }
+        int acc[2 * R + 1];
+#pragma unroll
+        for (int i = 0; i <= 2 * R; ++i) {
+            const int c = __builtin_amdgcn_readlane(t0[i], 60);
+            acc[i] = wave_sum_i32(abs(t0[i] - c) + (in1 ? abs(t1[i] - c) : 0));
+        }
+        int bestDist = 2147483647, bestinc = 0;
+#pragma unroll
+        for (int i = 0; i <= 2 * R; ++i) if (acc[i] < bestDist) { bestDist = acc[i]; bestinc = i - R; }
+        int prev = 0, next = 0;
+#pragma unroll
+        for (int i = 1; i < 2 * R; ++i) if (i - R == bestinc) { prev = acc[i - 1]; next = acc[i + 1]; }
+        if (lane == src) { r_best = bestDist; r_inc = bestinc; r_prev = prev; r_next = next; }
+    }
+    // every lane: parabola fit and disparity test of its own keypoint (:600-623)
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_s = -1;
+    if (cand && r_inc != -R && r_inc != R) {
+        const float d1 = (float)r_prev, d2 = (float)r_best, d3 = (float)r_next;
+        const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+        if (!(deltaR < -1.f || deltaR > 1.f)) {
+            float bestuR = __fmul_rn(lscale, __fadd_rn(__fadd_rn(scaleduR0, (float)r_inc), deltaR));
+            float disparity = __fsub_rn(kx, bestuR);
+            if (disparity >= min_d && disparity < max_d) {
+                if (disparity <= 0.f) { disparity = 0.01f; bestuR = (float)((double)kx - 0.01); }
+                out_d = __fdiv_rn(bf, disparity);
+                out_u = bestuR;
+                out_s = r_best;
+            }
+        }
+    }
+    if (mine) { uright[row] = out_u; depth[row] = out_d; sad[row] = out_s; }
 }
 
 // Median filter of the accepted SAD distances (src/Frame.cc:626-639).  The reference sorts (distance, left index) pairs
 // and uses the distance of element size/2.
+constexpr int kMedianRegs = 24;      // distances a lane keeps in registers: pairs of up to 64 * 24 left keypoints take the fast path
 __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict__ nl_arr, int cap, const int32_t* __restrict__ sad,
                                                        float* __restrict__ uright, float* __restrict__ depth, int n_pairs)
 {
     // one wavefront per pair; the median (element size/2 of the sorted distances, src/Frame.cc:626-629) is a value, so it
-    // is found by bisection on the value with a count per step: no sort, no workgroup barrier
+    // is found by bisection on the value with a count per step: no sort, no workgroup barrier.  The distances are read
+    // once and kept in registers (rejected ones as -1 -> 0x7FFFFFFF, never counted); only pairs with more keypoints than
+    // the registers hold walk device memory in every step.
     const int lane = threadIdx.x & 63;
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pair >= n_pairs) return;
     const int nl = min(nl_arr[pair], cap);
     const size_t base = (size_t)pair * cap;
+    const bool in_regs = nl <= 64 * kMedianRegs;
+    int mine[kMedianRegs];
     int nv = 0;
-    for (int i = lane; i < nl; i += 64) nv += sad[base + i] >= 0;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kMedianRegs; ++k) {
+            const int i = lane + 64 * k;
+            const int sv = i < nl ? sad[base + i] : -1;
+            mine[k] = sv >= 0 ? sv : 0x7FFFFFFF;
+            nv += sv >= 0;
+        }
+    } else {
+        for (int i = lane; i < nl; i += 64) nv += sad[base + i] >= 0;
+    }
     nv = wave_sum_i32(nv);
     if (nv == 0) return;
     const int kth = nv / 2;
@@ -1785,14 +1837,27 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict
     while (lo < hi) {
         const int v = lo + ((hi - lo) >> 1);
         int cnt = 0;
-        for (int i = lane; i < nl; i += 64) { const int sv = sad[base + i]; cnt += sv >= 0 && sv <= v; }
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kMedianRegs; ++k) cnt += mine[k] <= v;
+        } else {
+            for (int i = lane; i < nl; i += 64) { const int sv = sad[base + i]; cnt += sv >= 0 && sv <= v; }
+        }
         cnt = wave_sum_i32(cnt);
         if (cnt > kth) hi = v; else lo = v + 1;
     }
     const float thDist = 1.5f * 1.4f * (float)lo;
-    for (int i = lane; i < nl; i += 64) {
-        const int sv = sad[base + i];
-        if (sv >= 0 && !((float)sv < thDist)) { uright[base + i] = -1.0f; depth[base + i] = -1.0f; }
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kMedianRegs; ++k) {
+            const int i = lane + 64 * k;
+            if (mine[k] != 0x7FFFFFFF && !((float)mine[k] < thDist)) { uright[base + i] = -1.0f; depth[base + i] = -1.0f; }
+        }
+    } else {
+        for (int i = lane; i < nl; i += 64) {
+            const int sv = sad[base + i];
+            if (sv >= 0 && !((float)sv < thDist)) { uright[base + i] = -1.0f; depth[base + i] = -1.0f; }
+        }
     }
 }
 
@@ -2632,7 +2697,7 @@ int orbx_stereo_refine_batch_device(orbx_extractor* left, orbx_extractor* right,
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipStreamWaitEvent(st, left->ev_done, 0));       // the pyramids of both contexts' last batches must be complete
     HIP_CHECK(hipStreamWaitEvent(st, right->ev_done, 0));
-    hipLaunchKernelGGL(k_stereo_refine, dim3((cap_per_frame + 3) / 4, n_pairs), dim3(256), 0, st, left->d_pyr, right->d_pyr,
+    hipLaunchKernelGGL(k_stereo_refine, dim3((cap_per_frame + 4 * kRefineGroup - 1) / (4 * kRefineGroup), n_pairs), dim3(256), 0, st, left->d_pyr, right->d_pyr,
                        (unsigned long long)left->geo.pyr_bytes, left->d_lv, left->geo.nlevels, d_kl, d_nl, d_kr, cap_per_frame,
                        d_best_dist, d_best_idx, bf, min_d, max_d, d_uright, d_depth, d_sad);
     hipLaunchKernelGGL(k_stereo_median, dim3((n_pairs + 3) / 4), dim3(256), 0, st, d_nl, cap_per_frame, d_sad, d_uright, d_depth, n_pairs);

@@ -238,12 +238,15 @@ __global__ __launch_bounds__(256) void k_csr_dist(const uint32_t* __restrict__ q
 // lists in a device-memory slice of the workgroup), then one thread per left keypoint walks the list of its row only.
 // The best candidate is the minimum of distance << 16 | index, which is what the reference's strict '<' over lists in
 // ascending index order keeps, so the order in which the lists are filled does not matter.
+// The index lists live in LDS when they fit the entries the launch reserved there (they do for the usual 1000-2000
+// keypoints: a walk is a chain of dependent reads, and from device memory each link costs a round trip); a left
+// keypoint's walk takes four list entries a turn, so that up to four descriptor fetches are in flight.
 constexpr int kStereoThreads = 1024;
 __global__ __launch_bounds__(kStereoThreads) void k_stereo(const orbx_keypoint* __restrict__ kl, const uint32_t* __restrict__ dl, const int32_t* __restrict__ nl_arr,
                                                 const orbx_keypoint* __restrict__ kr, const uint32_t* __restrict__ dr, const int32_t* __restrict__ nr_arr,
                                                 int cap, int nl_fixed, int nr_fixed,
                                                 const float* __restrict__ scale, int n_rows, float min_d, float max_d,
-                                                uint16_t* __restrict__ lists, unsigned long long list_stride,
+                                                uint16_t* __restrict__ lists, unsigned long long list_stride, int lds_list_entries,
                                                 int32_t* __restrict__ best_dist, int32_t* __restrict__ best_idx)
 {
     extern __shared__ int32_t s_mem[];
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(kStereoThreads) void k_stereo(const orbx_keypoint* 
     int32_t* s_fill = s_mem + (n_rows + 1);        // n_rows + 1: counts, then fill positions
     float* s_x = reinterpret_cast<float*>(s_mem + 2 * (n_rows + 1));      // right keypoint columns
     uint8_t* s_oct = reinterpret_cast<uint8_t*>(s_x + cap);               // right keypoint octaves
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_oct + ((cap + 15) & ~15));   // lds_list_entries index-list entries
     __shared__ int32_t s_part[256];
     const int tid = threadIdx.x, NT = blockDim.x;
     const int pair = blockIdx.x;
@@ -289,45 +293,59 @@ __global__ __launch_bounds__(kStereoThreads) void k_stereo(const orbx_keypoint* 
         for (int i = c0; i < c1; ++i) { const int c = s_fill[i]; s_start[i] = run; s_fill[i] = run; run += c; }
     }
     __syncthreads();
-    for (int i = tid; i < nr; i += NT) {
-        const orbx_keypoint k = kr[base + i];
-        const float r = __fmul_rn(2.0f, scale[k.octave]);
-        const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), n_rows - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
-        for (int yi = minr; yi <= maxr; ++yi) list[atomicAdd(&s_fill[yi], 1)] = (uint16_t)i;
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (int iL = tid; iL < nl; iL += NT) {
-        const orbx_keypoint k = kl[base + iL];
-        const int levelL = k.octave;
-        const int row = (int)k.y;                                   // vRowIndices[vL], :509-511
-        const float minU = __fsub_rn(k.x, max_d), maxU = __fsub_rn(k.x, min_d);
-        const bool rowok = row >= 0 && row < n_rows;
-        const int b = rowok ? s_start[row] : 0, e = rowok ? s_start[row + 1] : 0;
-        const bool skipped = e == b || (maxU < 0);                  // :513-520
-        uint32_t best = (100u << 16);                               // bestDist = TH_HIGH, bestIdxR = 0 (:522-523)
-        if (!skipped) {
-            uint32_t qv[8];
-            { const uint4* qp = reinterpret_cast<const uint4*>(dl + (base + iL) * 8);
-              const uint4 a = qp[0], c = qp[1];
-              qv[0] = a.x; qv[1] = a.y; qv[2] = a.z; qv[3] = a.w; qv[4] = c.x; qv[5] = c.y; qv[6] = c.z; qv[7] = c.w; }
-            for (int c = b; c < e; ++c) {
-                const int i = list[c];
-                const int o = s_oct[i];
-                if (o < levelL - 1 || o > levelL + 1) continue;
-                const float uR = s_x[i];
-                if (uR >= minU && uR <= maxU) {
-                    const uint4* tp = reinterpret_cast<const uint4*>(dr + (base + i) * 8);
-                    const uint4 lo = tp[0], hi = tp[1];
-                    const uint32_t d = __popc(qv[0] ^ lo.x) + __popc(qv[1] ^ lo.y) + __popc(qv[2] ^ lo.z) + __popc(qv[3] ^ lo.w) +
-                                       __popc(qv[4] ^ hi.x) + __popc(qv[5] ^ hi.y) + __popc(qv[6] ^ hi.z) + __popc(qv[7] ^ hi.w);
-                    best = min(best, (d << 16) | (uint32_t)i);
+    const int total_entries = s_start[n_rows];                      // (every thread reads the same word)
+    auto fill_and_walk = [&](auto* lst) __attribute__((always_inline)) {
+        for (int i = tid; i < nr; i += NT) {
+            const orbx_keypoint k = kr[base + i];
+            const float r = __fmul_rn(2.0f, scale[k.octave]);
+            const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), n_rows - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
+            for (int yi = minr; yi <= maxr; ++yi) lst[atomicAdd(&s_fill[yi], 1)] = (uint16_t)i;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int iL = tid; iL < nl; iL += NT) {
+            const orbx_keypoint k = kl[base + iL];
+            const int levelL = k.octave;
+            const int row = (int)k.y;                                   // vRowIndices[vL], :509-511
+            const float minU = __fsub_rn(k.x, max_d), maxU = __fsub_rn(k.x, min_d);
+            const bool rowok = row >= 0 && row < n_rows;
+            const int b = rowok ? s_start[row] : 0, e = rowok ? s_start[row + 1] : 0;
+            const bool skipped = e == b || (maxU < 0);                  // :513-520
+            uint32_t best = (100u << 16);                               // bestDist = TH_HIGH, bestIdxR = 0 (:522-523)
+            if (!skipped) {
+                uint32_t qv[8];
+                { const uint4* qp = reinterpret_cast<const uint4*>(dl + (base + iL) * 8);
+                  const uint4 a = qp[0], c = qp[1];
+                  qv[0] = a.x; qv[1] = a.y; qv[2] = a.z; qv[3] = a.w; qv[4] = c.x; qv[5] = c.y; qv[6] = c.z; qv[7] = c.w; }
+                for (int c = b; c < e; c += 4) {
+                    int idx[4]; bool ok[4]; uint4 lo[4], hi[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool in = c + u < e;
+                        const int i = in ? (int)lst[c + u] : 0;
+                        const int o = s_oct[i];
+                        const float uR = s_x[i];
+                        idx[u] = i;
+                        ok[u] = in && !(o < levelL - 1 || o > levelL + 1) && uR >= minU && uR <= maxU;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ok[u]) { const uint4* tp = reinterpret_cast<const uint4*>(dr + (base + idx[u]) * 8); lo[u] = tp[0]; hi[u] = tp[1]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ok[u]) {
+                            const uint32_t d = __popc(qv[0] ^ lo[u].x) + __popc(qv[1] ^ lo[u].y) + __popc(qv[2] ^ lo[u].z) + __popc(qv[3] ^ lo[u].w) +
+                                               __popc(qv[4] ^ hi[u].x) + __popc(qv[5] ^ hi[u].y) + __popc(qv[6] ^ hi[u].z) + __popc(qv[7] ^ hi[u].w);
+                            best = min(best, (d << 16) | (uint32_t)idx[u]);
+                        }
                 }
             }
+            best_dist[base + iL] = skipped ? -1 : (int)(best >> 16);
+            best_idx[base + iL] = skipped ? -1 : (int)(best & 0xFFFF);
         }
-        best_dist[base + iL] = skipped ? -1 : (int)(best >> 16);
-        best_idx[base + iL] = skipped ? -1 : (int)(best & 0xFFFF);
-    }
+    };
+    if (total_entries <= lds_list_entries) fill_and_walk(s_list);
+    else fill_and_walk(list);
 }
 
 // Windowed candidate generation on the device.  One wavefront per query walks the keypoints in grid order, 64 at a time:
@@ -864,7 +882,13 @@ static int stereo_band_rows(const float* scale_factors, int nlevels)
     for (int i = 0; i < nlevels; ++i) smax = std::max(smax, scale_factors[i]);
     return (int)(4.0f * smax) + 3;
 }
-static size_t stereo_lds_bytes(int n_rows, int cap) { return sizeof(int32_t) * 2 * ((size_t)n_rows + 1) + sizeof(float) * (size_t)cap + (size_t)cap + 16; }
+static size_t stereo_lds_bytes(int n_rows, int cap) { return sizeof(int32_t) * 2 * ((size_t)n_rows + 1) + sizeof(float) * (size_t)cap + (size_t)((cap + 15) & ~15) + 16; }
+// index-list entries kept in LDS behind the row table: what the lists can hold at most, up to 64 KB (two workgroups per CU still fit)
+static int stereo_lds_list_entries(size_t table_bytes, size_t list_stride)
+{
+    const size_t room = table_bytes < 150 * 1024 ? 150 * 1024 - table_bytes : 0;
+    return (int)std::min<size_t>(std::min<size_t>(list_stride, 32768), room / sizeof(uint16_t));
+}
 
 } // namespace
 
@@ -1227,13 +1251,15 @@ int orbx_stereo_match_batch_device(orbx_matcher* m, const orbx_keypoint* d_kl, c
     if ((rc = reserve(&m->stage[6], &m->stage_bytes[6], sizeof(float) * kMaxLevels))) return rc;
     const size_t list_stride = (size_t)cap_per_frame * stereo_band_rows(scale_factors, nlevels);
     if ((rc = reserve(&m->stage[7], &m->stage_bytes[7], sizeof(uint16_t) * list_stride * (size_t)n_pairs))) return rc;
-    const size_t lds = stereo_lds_bytes(n_rows, cap_per_frame);
-    if (n_rows < 1 || lds > 150 * 1024) { set_error("image rows / keypoint capacity too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
+    const size_t table_lds = stereo_lds_bytes(n_rows, cap_per_frame);
+    if (n_rows < 1 || table_lds > 150 * 1024) { set_error("image rows / keypoint capacity too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
+    const int lds_list = stereo_lds_list_entries(table_lds, list_stride);
+    const size_t lds = table_lds + sizeof(uint16_t) * (size_t)lds_list;
     HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_stereo), lds));
     HIP_CHECK(hipMemcpyAsync(m->stage[6], scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_stereo, dim3(n_pairs), dim3(kStereoThreads), lds, st, d_kl, (const uint32_t*)d_dl, d_nl,
                        d_kr, (const uint32_t*)d_dr, d_nr, cap_per_frame, 0, 0, (const float*)m->stage[6], n_rows, min_d, max_d,
-                       (uint16_t*)m->stage[7], (unsigned long long)list_stride, d_best_dist, d_best_idx);
+                       (uint16_t*)m->stage[7], (unsigned long long)list_stride, lds_list, d_best_dist, d_best_idx);
     HIP_CHECK(hipGetLastError());
     return ORBX_OK;
 }
@@ -1265,12 +1291,14 @@ int orbx_stereo_match(orbx_matcher* m, const orbx_keypoint* kl, const uint8_t* d
     HIP_CHECK(hipMemcpyAsync(m->stage[6], scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, m->stream));
     const size_t list_stride = (size_t)cap * stereo_band_rows(scale_factors, nlevels);
     if ((rc = reserve(&m->stage[7], &m->stage_bytes[7], sizeof(uint16_t) * list_stride))) return rc;
-    const size_t lds = stereo_lds_bytes(n_rows, cap);
-    if (n_rows < 1 || lds > 150 * 1024) { set_error("image rows / keypoint count too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
+    const size_t table_lds = stereo_lds_bytes(n_rows, cap);
+    if (n_rows < 1 || table_lds > 150 * 1024) { set_error("image rows / keypoint count too large for the row table in LDS"); return ORBX_ERR_BAD_ARG; }
+    const int lds_list = stereo_lds_list_entries(table_lds, list_stride);
+    const size_t lds = table_lds + sizeof(uint16_t) * (size_t)lds_list;
     HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_stereo), lds));
     hipLaunchKernelGGL(k_stereo, dim3(1), dim3(kStereoThreads), lds, m->stream, (const orbx_keypoint*)m->stage[0], (const uint32_t*)m->stage[1],
                        (const int32_t*)nullptr, (const orbx_keypoint*)m->stage[2], (const uint32_t*)m->stage[3], (const int32_t*)nullptr, cap, nl, nr,
-                       (const float*)m->stage[6], n_rows, min_d, max_d, (uint16_t*)m->stage[7], (unsigned long long)list_stride,
+                       (const float*)m->stage[6], n_rows, min_d, max_d, (uint16_t*)m->stage[7], (unsigned long long)list_stride, lds_list,
                        (int32_t*)m->stage[4], (int32_t*)m->stage[5]);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(best_dist, m->stage[4], sizeof(int32_t) * (size_t)nl, hipMemcpyDeviceToHost, m->stream));
