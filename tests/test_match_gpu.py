@@ -373,11 +373,15 @@ def test_stereo_match(vsa, oracle, matcher, stereo_features):
     assert (g[0] == -1).all()
 
 
-def test_stereo_pipeline_device_resident(vsa, oracle, matcher):
-    """The 752x480 stereo shape: left+right extraction then stereo Hamming, all buffers in HBM."""
+@pytest.mark.parametrize("nfeatures,lists_in_lds", [(1000, True), (1000, False), (2600, True)])
+def test_stereo_pipeline_device_resident(vsa, oracle, matcher, monkeypatch, nfeatures, lists_in_lds):
+    """The 752x480 stereo shape: left+right extraction then stereo Hamming, all buffers in HBM.  The row search with its
+    index lists in LDS and in device memory; 2600 features: more left keypoints than the median filter holds in registers."""
     torch = pytest.importorskip("torch")
     w, h, B = 752, 480, 2
-    p = vsa.make_params()
+    p = vsa.make_params(nfeatures=nfeatures)
+    if not lists_in_lds:
+        monkeypatch.setenv("ORBX_STEREO_LIST_IN_LDS", "0")
     exl = vsa.Extractor(p, w, h, max_batch=B, device=0)
     exr = vsa.Extractor(p, w, h, max_batch=B, device=0)
     pairs = [vsa.synth_stereo(30 + i, w, h) for i in range(B)]
@@ -410,11 +414,12 @@ def test_stereo_pipeline_device_resident(vsa, oracle, matcher):
                                    bd.data_ptr(), bi.data_ptr(), bf, 0.0, bf / mb, ur.data_ptr(), dp.data_ptr(), sad.data_ptr(),
                                    torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    oexl, oexr = oracle.Extractor(oracle.make_params()), oracle.Extractor(oracle.make_params())
+    oexl, oexr = oracle.Extractor(oracle.make_params(nfeatures=nfeatures)), oracle.Extractor(oracle.make_params(nfeatures=nfeatures))
     for i in range(B):
         kl, dl = oexl.extract(pairs[i][0]); kr, dr = oexr.extract(pairs[i][1])
         nl = int(out["l"][2][i])
         assert nl == len(kl) and int(out["r"][2][i]) == len(kr)
+        assert nfeatures < 2000 or nl > 64 * 24
         assert np.array_equal(out["l"][1][i, :nl].cpu().numpy(), dl)
         o = oracle.stereo_match(kl, dl, kr, dr, scale, h, 0.0, bf / mb)
         assert np.array_equal(bd[i, :nl].cpu().numpy(), o[0]) and np.array_equal(bi[i, :nl].cpu().numpy(), o[1])

@@ -886,6 +886,7 @@ static size_t stereo_lds_bytes(int n_rows, int cap) { return sizeof(int32_t) * 2
 // index-list entries kept in LDS behind the row table: what the lists can hold at most, up to 64 KB (two workgroups per CU still fit)
 static int stereo_lds_list_entries(size_t table_bytes, size_t list_stride)
 {
+    if (const char* e = getenv("ORBX_STEREO_LIST_IN_LDS")) if (atoi(e) == 0) return 0;      // test switch: lists in device memory
     const size_t room = table_bytes < 150 * 1024 ? 150 * 1024 - table_bytes : 0;
     return (int)std::min<size_t>(std::min<size_t>(list_stride, 32768), room / sizeof(uint16_t));
 }
