@@ -84,6 +84,24 @@ def test_blur_rounding_simd_mode(vsa, oracle):
     ex.close()
 
 
+@pytest.mark.parametrize("own_blur", ["0", "1"])
+@pytest.mark.parametrize("cfg,blur_rounding", [((640, 480, 1000, 8, 1.2, 20, 7, 21), 0), ((752, 480, 1200, 8, 1.2, 20, 7, 22), 1),
+                                               ((1920, 1080, 2000, 8, 1.2, 20, 7, 23), 0), ((321, 243, 500, 5, 1.3, 25, 9, 24), 1)],
+                         ids=["vga", "euroc_simd_rounding", "fullhd", "odd_simd_rounding"])
+def test_descriptor_window_blur_forms(vsa, oracle, monkeypatch, cfg, blur_rounding, own_blur):
+    """The two forms of the blur behind the descriptors -- every level blurred by its own kernel, or each keypoint's window
+    blurred inside the describing kernel (the library picks by pixels per keypoint; ORBX_OWN_BLUR forces one) -- against the
+    oracle, in both rounding modes; the blurred levels stay available to the debug download in either form."""
+    monkeypatch.setenv("ORBX_OWN_BLUR", own_blur)
+    _, ex, oex, kps, desc, okps, odesc = run_both(vsa, oracle, cfg, blur_rounding=blur_rounding)
+    assert len(kps) == len(okps) and len(kps) > 100
+    assert np.array_equal(kps["x"], okps["x"]) and np.array_equal(kps["y"], okps["y"]) and np.array_equal(kps["angle"], okps["angle"])
+    assert np.array_equal(desc, odesc), f"{np.count_nonzero(np.any(desc != odesc, axis=1))} descriptors differ"
+    got, want = ex.debug_blurred_level(0, 1), oex.level_blurred(1)
+    assert want is None or np.array_equal(got, want)
+    ex.close()
+
+
 def test_trig_modes_exhaustive(vsa, oracle):
     """cos / sin of the keypoint angle (src/ORBextractor.cc:111-112) for EVERY float angle in [0, 360): the device under
     trig_mode 1 and 2 against this host's libm cosf / sinf (oracle trig_mode 3, the function the reference calls), and

@@ -1485,14 +1485,24 @@ __device__ __constant__ __align__(16) PatternF c_pattern_f = make_pattern_f();
 // the lane (disc weights, load offsets in units of rows and bytes) is set up once.
 constexpr int kKpPerWave = 4;
 
+// kOwnBlur: there are no blurred levels -- the wavefront fetches the 43x43 pixels of the unblurred level around its keypoint
+// and blurs the 37x37 window itself, in LDS, with the arithmetic of k_blur (same taps, same single rounding, same groups
+// of four columns).  That is about 1.6 k blurred pixels per keypoint: cheaper than blurring every level when the image
+// has many more pixels than keypoints x 1.6 k (3840x2160 with 8000 features), dearer otherwise (orbx_extractor::own_blur).
+constexpr int kRawW = 43, kRawRows = 44;           // window rows fetched (one spare row: the last row pair reads it, nothing uses it)
+constexpr int kHGroups = 11;                       // aligned groups of four columns that hold the 37 window columns
+template <bool kOwnBlur>
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
                                                   unsigned long long blur_bytes, const DevLevel* __restrict__ lv, int nlevels,
                                                   const uint32_t* __restrict__ lvlkp, int kp_total,
                                                   const int32_t* __restrict__ lvlcnt,
                                                   orbx_keypoint* __restrict__ okp, uint8_t* __restrict__ odesc,
-                                                  int32_t* __restrict__ ocount, int cap_per_frame, int n_frames, int trig_mode)
+                                                  int32_t* __restrict__ ocount, int cap_per_frame, int n_frames, int trig_mode, int ex_blur_mode)
 {
-    __shared__ __align__(16) uint4 s_win[4][kBlurW * kWinChunks + 1];
+    // (own blur: one leading chunk, so that the group left of the first one can be read, then the raw rows; the blurred
+    // window later takes the place of the raw rows)
+    __shared__ __align__(16) uint4 s_win[4][kOwnBlur ? 1 + kRawRows * kWinChunks : kBlurW * kWinChunks + 1];
+    __shared__ __align__(16) uint4 s_h[kOwnBlur ? 4 : 1][kOwnBlur ? (kRawRows / 2) * kHGroups : 1];   // horizontal sums, two rows per word
     __shared__ __align__(16) float4 s_pat[256];
     __shared__ __align__(16) uint32_t s_ic[256];
     // results of a wavefront's four keypoints, stored together at the end: 4 x 32 descriptor bytes, 4 x 7 record words
@@ -1514,7 +1524,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     __syncthreads();
     const int slot0 = ((int)chunk * 4 + wave) * kKpPerWave;
     if (slot0 >= kp_total) return;
-    uint4* win = s_win[wave];
+    uint4* win = s_win[wave] + (kOwnBlur ? 1 : 0);
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
 
     // lane constants.  Window: 16-byte chunk l = lane, lane + 64 of the 37 x 3 chunks -> (row, byte).  Disc: lane
@@ -1581,6 +1591,17 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         if (jlevel[q] < 0) return;
         const DevLevel& L = lv[jlevel[q]];
         int kx, ky; key_xy(q, kx, ky);
+        if constexpr (kOwnBlur) {
+            // rows ky-21..ky+21 of the unblurred level, the four 16-byte chunks from the one that holds column kx-21: slot
+            // lane + 64 k is chunk (slot & 3) of row slot >> 2, so four lanes read 64 contiguous bytes
+            const uint8_t* rsrc = pyr + (unsigned long long)frame * pyr_bytes + L.roi + (long long)(ky - 21) * L.stride + (long long)((kx - 21) & ~15);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t sl = (uint32_t)lane + 64u * k;
+                if ((sl >> 2) < (uint32_t)kRawW) f.w[k] = *reinterpret_cast<const u32x4*>(rsrc + (__umul24(sl >> 2, (uint32_t)L.stride) + 16u * (sl & 3u)));
+            }
+            return;
+        }
         // blurred window rows ky-18..ky+18, the four 16-byte columns from the one holding column kx-18, out of the
         // tiled level: tile (y >> 3, column) holds row y at byte 16 * (y & 7).  The 192 slots of the three loads walk
         // the memory order -- column, tile row (six cover the 37 rows wherever they start), row inside the tile -- so every
@@ -1636,6 +1657,78 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         wave_sync();        // the previous keypoint's tests have read the window
         u32x4* winv = reinterpret_cast<u32x4*>(win);
         int kx, ky; key_xy(q, kx, ky);
+        if constexpr (kOwnBlur) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t sl = (uint32_t)lane + 64u * k;
+                if ((sl >> 2) < (uint32_t)kRawW) winv[sl] = f.w[k];
+            }
+            wave_sync();
+            const DevLevel& L = lv[jlevel[q]];
+            const uint32_t a = (uint32_t)(kx - 21) & 15u;              // byte of column kx-21 inside its chunk row
+            const uint32_t G0 = (a + 3u) >> 2;                         // group of window column 0 (its centre byte is a + 3)
+            const int xg0 = ((kx - 21) & ~15) + 4 * (int)G0;           // image column of that group's first pixel
+            const uint32_t* rawd = reinterpret_cast<const uint32_t*>(win);
+            constexpr uint32_t T0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), T1 = 49u | (34u << 8) | (18u << 16);
+            constexpr uint32_t A0 = (18u << 8) | (34u << 16) | (49u << 24), B0 = 55u | (49u << 8) | (34u << 16) | (18u << 24);
+            constexpr uint32_t A1 = (18u << 16) | (34u << 24), B1 = 49u | (55u << 8) | (49u << 16) | (34u << 24), C1 = 18u;
+            constexpr uint32_t A2 = 18u << 24, B2 = 34u | (49u << 8) | (55u << 16) | (49u << 24), C2 = 34u | (18u << 8);
+            constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
+            constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
+            // horizontal pass: task = (row pair, group); per pixel the sums of rows 2p | 2p+1 << 16, as in k_blur
+            uint4* hv = s_h[wave];
+#pragma unroll
+            for (int it = 0; it < ((kRawRows / 2) * kHGroups + 63) / 64; ++it) {
+                const uint32_t t = (uint32_t)lane + 64u * it;
+                if (t < (uint32_t)((kRawRows / 2) * kHGroups)) {
+                    const uint32_t pr = (t * 5958u) >> 16, gi = t - pr * (uint32_t)kHGroups;      // t / 11 for t < 256
+                    uint32_t h[2][4];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const uint32_t* rp = rawd + ((2u * pr + r) * 16u + G0 + gi);
+                        const uint32_t ta = rp[-1], tb = rp[0], tc = rp[1];
+                        h[r][0] = __builtin_amdgcn_udot4(tb, B0, __builtin_amdgcn_udot4(ta, A0, 0u, false), false);
+                        h[r][1] = __builtin_amdgcn_udot4(tc, C1, __builtin_amdgcn_udot4(tb, B1, __builtin_amdgcn_udot4(ta, A1, 0u, false), false), false);
+                        h[r][2] = __builtin_amdgcn_udot4(tc, C2, __builtin_amdgcn_udot4(tb, B2, __builtin_amdgcn_udot4(ta, A2, 0u, false), false), false);
+                        h[r][3] = __builtin_amdgcn_udot4(tc, T1, __builtin_amdgcn_udot4(tb, T0, 0u, false), false);
+                    }
+                    hv[t] = make_uint4(h[0][0] | (h[1][0] << 16), h[0][1] | (h[1][1] << 16), h[0][2] | (h[1][2] << 16), h[0][3] | (h[1][3] << 16));
+                }
+            }
+            wave_sync();
+            // vertical pass: task = (pair of window rows 2m, 2m+1, group) over the row pairs m .. m+3; the blurred bytes go
+            // where the raw ones were, window column c at byte a + 3 + c of its 64-byte row
+            uint32_t* outd = reinterpret_cast<uint32_t*>(win);
+            const bool round_even = ex_blur_mode != 0;
+#pragma unroll
+            for (int it = 0; it < (((kBlurW + 1) / 2) * kHGroups + 63) / 64; ++it) {
+                const uint32_t t = (uint32_t)lane + 64u * it;
+                if (t < (uint32_t)(((kBlurW + 1) / 2) * kHGroups)) {
+                    const uint32_t m = (t * 5958u) >> 16, gi = t - m * (uint32_t)kHGroups;
+                    const uint4 p0 = hv[m * kHGroups + gi], p1 = hv[(m + 1) * kHGroups + gi], p2 = hv[(m + 2) * kHGroups + gi], p3 = hv[(m + 3) * kHGroups + gi];
+                    const uint32_t d0[4] = {p0.x, p0.y, p0.z, p0.w}, d1[4] = {p1.x, p1.y, p1.z, p1.w}, d2[4] = {p2.x, p2.y, p2.z, p2.w}, d3[4] = {p3.x, p3.y, p3.z, p3.w};
+                    const bool even_ties = round_even && xg0 + 4 * (int)gi < (L.w & ~3);
+                    uint32_t te[4], to[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+#define ORBX_DOT2(a_, w_, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, (uint32_t)(a_)), __builtin_bit_cast(us16x2, (uint32_t)(w_)), acc, false)
+                        const uint32_t se = ORBX_DOT2(d3[k], E3, ORBX_DOT2(d2[k], E2, ORBX_DOT2(d1[k], E1, ORBX_DOT2(d0[k], E0, 0u))));
+                        const uint32_t so = ORBX_DOT2(d3[k], O3, ORBX_DOT2(d2[k], O2, ORBX_DOT2(d1[k], O1, ORBX_DOT2(d0[k], O0, 0u))));
+#undef ORBX_DOT2
+                        te[k] = se + (even_ties ? 32767u + ((se >> 16) & 1u) : 32768u);
+                        to[k] = so + (even_ties ? 32767u + ((so >> 16) & 1u) : 32768u);
+                    }
+                    const us16x2 lim = {255, 255};
+                    const uint32_t e01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[1], te[0], 0x07060302u)), lim));
+                    const uint32_t e23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[3], te[2], 0x07060302u)), lim));
+                    const uint32_t o01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[1], to[0], 0x07060302u)), lim));
+                    const uint32_t o23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(to[3], to[2], 0x07060302u)), lim));
+                    outd[(2u * m) * 16u + G0 + gi] = __builtin_amdgcn_perm(e23, e01, 0x06040200u);
+                    if (2u * m + 1u < (uint32_t)kBlurW) outd[(2u * m + 1u) * 16u + G0 + gi] = __builtin_amdgcn_perm(o23, o01, 0x06040200u);
+                }
+            }
+            return;
+        }
         const uint32_t off7 = (uint32_t)(ky - 18) & 7u;
         const uint32_t last = ((uint32_t)(kx - 18) & 15u) >= 12u ? 4u : 3u;
 #pragma unroll
@@ -1651,7 +1744,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         const float angle = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_angle), q));
         const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_a), q));
         const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_b), q));
-        const int wshift = (kx - 18) & 15;
+        const int wshift = kOwnBlur ? (int)((uint32_t)(kx - 21) & 15u) + 3 : (kx - 18) & 15;
         wave_sync();
         // cvRound by adding 1.5 * 2^23: the low bits of the sum's encoding are the rounded integer (ties to even)
         constexpr float kMagic = 12582912.f;
@@ -1985,6 +2078,7 @@ struct orbx_extractor {
     hipEvent_t ev[ORBX_STAGE_COUNT + 1] = {};
     hipEvent_t ev_done = nullptr;        // recorded behind the last kernel of every batch, on the stream the batch ran on
     hipEvent_t ev_fork = nullptr;        // orbx_extract_batch_device_multi: recorded on the caller's stream, waited for by the contexts' streams
+    bool own_blur = false;               // k_describe blurs each keypoint's window itself; no blurred levels (see k_describe)
     void* sr_dev = nullptr; uint8_t* sr_pin = nullptr; size_t sr_bytes = 0;   // staging of the host form of the stereo refinement
     hipStream_t copy_stream = nullptr;   // uploads of the chunked host batch path
     std::vector<hipEvent_t> chunk_ev;    // one per chunk: upload done
@@ -2118,6 +2212,16 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
         HIP_CHECK(hipMalloc(&ex->d_octmem, ex->oct_gstride * geo.nlevels * (size_t)max_batch));
     }
     HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<false>), ex->oct_lds));
+    {
+        // own blur when blurring every keypoint's 43 x 37 + 37 x 37 window costs less than blurring every level.  Measured:
+        // a window costs about as much as 1400 level pixels (640x480 / 1000 features, 940 pixels per keypoint: 781 -> 843 us
+        // per 256 frames with own blur; 3840x2160 / 8000, 3300 per keypoint: 2360 -> 2117 us per 32 frames, 14.3 k ->
+        // 17.0 k frames/s on four contexts).  ORBX_OWN_BLUR=0 / 1 forces a form (tests, A/B runs).
+        long pyr_px = 0;
+        for (int l = 0; l < geo.nlevels; ++l) pyr_px += (long)geo.lv[l].w * geo.lv[l].h;
+        ex->own_blur = (long)geo.kp_total * 2000 < pyr_px;
+        if (const char* e = getenv("ORBX_OWN_BLUR")) ex->own_blur = atoi(e) != 0;
+    }
     HIP_CHECK(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&ex->ev_done, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ex->ev_fork, hipEventDisableTiming));
@@ -2290,7 +2394,8 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
         // the blurred levels are only read by k_describe, but the blur runs here, next to the pyramid it reads: with the
         // blur directly in front of it k_describe took 6 % longer (measured, 187 against 176 us per 256 frames)
         dim3 gblur(frame_chunk_grid((unsigned)ex->n_blur_chunks, B));
-        if (ex->params.blur_rounding)
+        if (ex->own_blur) {}
+        else if (ex->params.blur_rounding)
             hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, ex->d_blur_chunks, B);
         else
             hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, ex->d_blur_chunks, B);
@@ -2326,8 +2431,12 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
     {
         dim3 grid(frame_chunk_grid((G.kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), B));
-        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels,
-                           lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B, ex->params.trig_mode);
+        if (ex->own_blur)
+            hipLaunchKernelGGL(k_describe<true>, grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels,
+                               lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B, ex->params.trig_mode, ex->params.blur_rounding);
+        else
+            hipLaunchKernelGGL(k_describe<false>, grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels,
+                               lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B, ex->params.trig_mode, ex->params.blur_rounding);
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[5], st));
     HIP_CHECK(hipGetLastError());
@@ -2779,6 +2888,17 @@ int orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* 
     if (dst_stride < L.w) return ORBX_ERR_BAD_ARG;
     HIP_CHECK(hipSetDevice(ex->device));
     HIP_CHECK(sync_context(ex));
+    if (ex->own_blur) {
+        // this context's k_describe blurs its windows itself: make the blurred levels of the last batch now
+        const Geometry& G = ex->geo;
+        dim3 gblur(frame_chunk_grid((unsigned)ex->n_blur_chunks, ex->max_batch));
+        if (ex->params.blur_rounding)
+            hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, ex->stream, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, ex->d_blur_chunks, ex->max_batch);
+        else
+            hipLaunchKernelGGL(k_blur<0>, gblur, dim3(256), 0, ex->stream, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, ex->d_blur_chunks, ex->max_batch);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ex->stream));
+    }
     // the device copy is tiled (8 rows x 16 bytes per 128-byte tile, tpr tiles per tile row)
     const size_t bytes = (size_t)((L.h + 7) / 8) * L.tpr * 128;
     std::vector<uint8_t> tiled(bytes);
