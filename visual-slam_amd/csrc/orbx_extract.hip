@@ -1491,13 +1491,13 @@ constexpr int kKpPerWave = 4;
 // has many more pixels than keypoints x 1.6 k (3840x2160 with 8000 features), dearer otherwise (orbx_extractor::own_blur).
 constexpr int kRawW = 43, kRawRows = 44;           // window rows fetched (one spare row: the last row pair reads it, nothing uses it)
 constexpr int kHGroups = 11;                       // aligned groups of four columns that hold the 37 window columns
-template <bool kOwnBlur>
+template <bool kOwnBlur, int kBlurMode>
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
                                                   unsigned long long blur_bytes, const DevLevel* __restrict__ lv, int nlevels,
                                                   const uint32_t* __restrict__ lvlkp, int kp_total,
                                                   const int32_t* __restrict__ lvlcnt,
                                                   orbx_keypoint* __restrict__ okp, uint8_t* __restrict__ odesc,
-                                                  int32_t* __restrict__ ocount, int cap_per_frame, int n_frames, int trig_mode, int ex_blur_mode)
+                                                  int32_t* __restrict__ ocount, int cap_per_frame, int n_frames, int trig_mode)
 {
     // (own blur: one leading chunk, so that the group left of the first one can be read, then the raw rows; the blurred
     // window later takes the place of the raw rows)
@@ -1699,7 +1699,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             // vertical pass: task = (pair of window rows 2m, 2m+1, group) over the row pairs m .. m+3; the blurred bytes go
             // where the raw ones were, window column c at byte a + 3 + c of its 64-byte row
             uint32_t* outd = reinterpret_cast<uint32_t*>(win);
-            const bool round_even = ex_blur_mode != 0;
 #pragma unroll
             for (int it = 0; it < (((kBlurW + 1) / 2) * kHGroups + 63) / 64; ++it) {
                 const uint32_t t = (uint32_t)lane + 64u * it;
@@ -1707,16 +1706,21 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
                     const uint32_t m = (t * 5958u) >> 16, gi = t - m * (uint32_t)kHGroups;
                     const uint4 p0 = hv[m * kHGroups + gi], p1 = hv[(m + 1) * kHGroups + gi], p2 = hv[(m + 2) * kHGroups + gi], p3 = hv[(m + 3) * kHGroups + gi];
                     const uint32_t d0[4] = {p0.x, p0.y, p0.z, p0.w}, d1[4] = {p1.x, p1.y, p1.z, p1.w}, d2[4] = {p2.x, p2.y, p2.z, p2.w}, d3[4] = {p3.x, p3.y, p3.z, p3.w};
-                    const bool even_ties = round_even && xg0 + 4 * (int)gi < (L.w & ~3);
+                    const bool even_ties = kBlurMode != 0 && xg0 + 4 * (int)gi < (L.w & ~3);
                     uint32_t te[4], to[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
 #define ORBX_DOT2(a_, w_, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(us16x2, (uint32_t)(a_)), __builtin_bit_cast(us16x2, (uint32_t)(w_)), acc, false)
-                        const uint32_t se = ORBX_DOT2(d3[k], E3, ORBX_DOT2(d2[k], E2, ORBX_DOT2(d1[k], E1, ORBX_DOT2(d0[k], E0, 0u))));
-                        const uint32_t so = ORBX_DOT2(d3[k], O3, ORBX_DOT2(d2[k], O2, ORBX_DOT2(d1[k], O1, ORBX_DOT2(d0[k], O0, 0u))));
+                        // the rounding constant of (sum + 32768) >> 16 rides in as the accumulator's start value
+                        constexpr uint32_t kStart = kBlurMode == 0 ? 32768u : 0u;
+                        const uint32_t se = ORBX_DOT2(d3[k], E3, ORBX_DOT2(d2[k], E2, ORBX_DOT2(d1[k], E1, ORBX_DOT2(d0[k], E0, kStart))));
+                        const uint32_t so = ORBX_DOT2(d3[k], O3, ORBX_DOT2(d2[k], O2, ORBX_DOT2(d1[k], O1, ORBX_DOT2(d0[k], O0, kStart))));
 #undef ORBX_DOT2
-                        te[k] = se + (even_ties ? 32767u + ((se >> 16) & 1u) : 32768u);
-                        to[k] = so + (even_ties ? 32767u + ((so >> 16) & 1u) : 32768u);
+                        if (kBlurMode == 0) { te[k] = se; to[k] = so; }
+                        else {
+                            te[k] = se + (even_ties ? 32767u + ((se >> 16) & 1u) : 32768u);
+                            to[k] = so + (even_ties ? 32767u + ((so >> 16) & 1u) : 32768u);
+                        }
                     }
                     const us16x2 lim = {255, 255};
                     const uint32_t e01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us16x2, __builtin_amdgcn_perm(te[1], te[0], 0x07060302u)), lim));
@@ -2431,12 +2435,12 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[4], st));
     {
         dim3 grid(frame_chunk_grid((G.kp_total + 4 * kKpPerWave - 1) / (4 * kKpPerWave), B));
-        if (ex->own_blur)
-            hipLaunchKernelGGL(k_describe<true>, grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels,
-                               lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B, ex->params.trig_mode, ex->params.blur_rounding);
-        else
-            hipLaunchKernelGGL(k_describe<false>, grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, G.nlevels,
-                               lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B, ex->params.trig_mode, ex->params.blur_rounding);
+#define ORBX_LAUNCH_DESCRIBE(OWN, MODE) hipLaunchKernelGGL((k_describe<OWN, MODE>), grid, dim3(256), 0, st, pyr, blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, \
+                ex->d_lv, G.nlevels, lvlkp, G.kp_total, lvlcnt, d_kps, d_desc, d_counts, cap_per_frame, B, ex->params.trig_mode)
+        if (!ex->own_blur) ORBX_LAUNCH_DESCRIBE(false, 0);
+        else if (ex->params.blur_rounding) ORBX_LAUNCH_DESCRIBE(true, 1);
+        else ORBX_LAUNCH_DESCRIBE(true, 0);
+#undef ORBX_LAUNCH_DESCRIBE
     }
     if (prof) HIP_CHECK(hipEventRecord(ex->ev[5], st));
     HIP_CHECK(hipGetLastError());
