@@ -1490,7 +1490,7 @@ constexpr int kKpPerWave = 4;
 // of four columns).  That is about 1.6 k blurred pixels per keypoint: cheaper than blurring every level when the image
 // has many more pixels than keypoints x 1.6 k (3840x2160 with 8000 features), dearer otherwise (orbx_extractor::own_blur).
 constexpr int kRawW = 43, kRawRows = 44;           // window rows fetched (one spare row: the last row pair reads it, nothing uses it)
-constexpr int kHGroups = 11;                       // aligned groups of four columns that hold the 37 window columns
+constexpr int kHGroups = 10;                       // aligned groups of four columns that hold the 37 window columns (first one: the group of byte a + 3)
 template <bool kOwnBlur, int kBlurMode>
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blr, unsigned long long pyr_bytes,
                                                   unsigned long long blur_bytes, const DevLevel* __restrict__ lv, int nlevels,
@@ -1675,13 +1675,14 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             constexpr uint32_t A2 = 18u << 24, B2 = 34u | (49u << 8) | (55u << 16) | (49u << 24), C2 = 34u | (18u << 8);
             constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
             constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
+            static_assert(kHGroups == 10 && (kRawRows / 2) * kHGroups <= 256, "the reciprocal below divides by ten, for task numbers under 256");
             // horizontal pass: task = (row pair, group); per pixel the sums of rows 2p | 2p+1 << 16, as in k_blur
             uint4* hv = s_h[wave];
 #pragma unroll
             for (int it = 0; it < ((kRawRows / 2) * kHGroups + 63) / 64; ++it) {
                 const uint32_t t = (uint32_t)lane + 64u * it;
                 if (t < (uint32_t)((kRawRows / 2) * kHGroups)) {
-                    const uint32_t pr = (t * 5958u) >> 16, gi = t - pr * (uint32_t)kHGroups;      // t / 11 for t < 256
+                    const uint32_t pr = (t * 6554u) >> 16, gi = t - pr * (uint32_t)kHGroups;      // t / 10 for t < 256
                     uint32_t h[2][4];
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
@@ -1703,7 +1704,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
             for (int it = 0; it < (((kBlurW + 1) / 2) * kHGroups + 63) / 64; ++it) {
                 const uint32_t t = (uint32_t)lane + 64u * it;
                 if (t < (uint32_t)(((kBlurW + 1) / 2) * kHGroups)) {
-                    const uint32_t m = (t * 5958u) >> 16, gi = t - m * (uint32_t)kHGroups;
+                    const uint32_t m = (t * 6554u) >> 16, gi = t - m * (uint32_t)kHGroups;
                     const uint4 p0 = hv[m * kHGroups + gi], p1 = hv[(m + 1) * kHGroups + gi], p2 = hv[(m + 2) * kHGroups + gi], p3 = hv[(m + 3) * kHGroups + gi];
                     const uint32_t d0[4] = {p0.x, p0.y, p0.z, p0.w}, d1[4] = {p1.x, p1.y, p1.z, p1.w}, d2[4] = {p2.x, p2.y, p2.z, p2.w}, d3[4] = {p3.x, p3.y, p3.z, p3.w};
                     const bool even_ties = kBlurMode != 0 && xg0 + 4 * (int)gi < (L.w & ~3);
