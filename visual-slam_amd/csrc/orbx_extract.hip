@@ -1693,7 +1693,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
                         h[r][2] = __builtin_amdgcn_udot4(tc, C2, __builtin_amdgcn_udot4(tb, B2, __builtin_amdgcn_udot4(ta, A2, 0u, false), false), false);
                         h[r][3] = __builtin_amdgcn_udot4(tc, T1, __builtin_amdgcn_udot4(tb, T0, 0u, false), false);
                     }
-                    hv[t] = make_uint4(h[0][0] | (h[1][0] << 16), h[0][1] | (h[1][1] << 16), h[0][2] | (h[1][2] << 16), h[0][3] | (h[1][3] << 16));
+                    // (the pairing as one byte select: the compiler makes a shift and an or of `a | b << 16`; not as inline
+                    // assembly -- behind a dot product the compiler must see the reader to keep the required distance)
+                    hv[t] = make_uint4(__builtin_amdgcn_perm(h[1][0], h[0][0], 0x05040100u), __builtin_amdgcn_perm(h[1][1], h[0][1], 0x05040100u),
+                                       __builtin_amdgcn_perm(h[1][2], h[0][2], 0x05040100u), __builtin_amdgcn_perm(h[1][3], h[0][3], 0x05040100u));
                 }
             }
             wave_sync();
