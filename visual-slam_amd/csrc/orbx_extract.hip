@@ -2221,13 +2221,14 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     }
     HIP_CHECK((hipError_t)raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<false>), ex->oct_lds));
     {
-        // own blur when blurring every keypoint's 43 x 37 + 37 x 37 window costs less than blurring every level.  Measured:
-        // a window costs about as much as 1400 level pixels (640x480 / 1000 features, 940 pixels per keypoint: 781 -> 843 us
-        // per 256 frames with own blur; 3840x2160 / 8000, 3300 per keypoint: 2360 -> 2117 us per 32 frames, 14.3 k ->
-        // 17.0 k frames/s on four contexts).  ORBX_OWN_BLUR=0 / 1 forces a form (tests, A/B runs).
+        // own blur when blurring every keypoint's 43 x 37 + 37 x 37 window costs less than blurring every level.  Measured
+        // (us per launch, blurred levels -> own blur): a window costs about as much as 950 level pixels -- 1241x376 / 2000
+        // features, 700 pixels per keypoint slot: 1221 -> 1284; 752x480 / 1200, 890: 887 -> 882; 640x480 / 1000, 940: 780 ->
+        // 773 (four contexts: no difference); 1920x1080 / 2000, 3300: 1147 -> 989; 3840x2160 / 8000, 3300: 2360 -> 2043,
+        // 14.3 k -> 17 k frames/s on four contexts.  ORBX_OWN_BLUR=0 / 1 forces a form (tests, A/B runs).
         long pyr_px = 0;
         for (int l = 0; l < geo.nlevels; ++l) pyr_px += (long)geo.lv[l].w * geo.lv[l].h;
-        ex->own_blur = (long)geo.kp_total * 2000 < pyr_px;
+        ex->own_blur = (long)geo.kp_total * 1200 < pyr_px;
         if (const char* e = getenv("ORBX_OWN_BLUR")) ex->own_blur = atoi(e) != 0;
     }
     HIP_CHECK(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
