@@ -2290,8 +2290,10 @@ int orbx_extractor_create(const orbx_params* p, int width, int height, int max_b
     if (!geo.rgb.empty()) HIP_CHECK(hipMemcpy(ex->d_rgb, geo.rgb.data(), sizeof(ResizeGroupB) * geo.rgb.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&ex->d_pyr, geo.pyr_bytes * B + 256));
     HIP_CHECK(hipMemset(ex->d_pyr, 0, geo.pyr_bytes * B + 256));
-    HIP_CHECK(hipMalloc(&ex->d_blur, geo.blur_bytes * B + 256));
-    HIP_CHECK(hipMemset(ex->d_blur, 0, geo.blur_bytes * B + 256));
+    if (!ex->own_blur) {         // (an own-blur context gets its blurred levels when the debug download first asks for them)
+        HIP_CHECK(hipMalloc(&ex->d_blur, geo.blur_bytes * B + 256));
+        HIP_CHECK(hipMemset(ex->d_blur, 0, geo.blur_bytes * B + 256));
+    }
     HIP_CHECK(hipMalloc(&ex->d_cand, sizeof(uint32_t) * (size_t)geo.cand_total * B));
     HIP_CHECK(hipMalloc(&ex->d_cellcnt, sizeof(uint16_t) * geo.cells.size() * B));
     HIP_CHECK(hipMalloc(&ex->d_keys, sizeof(uint32_t) * (size_t)ex->key_total * B));
@@ -2347,7 +2349,7 @@ static int launch_frames(orbx_extractor* ex, hipStream_t st, int f0, int B, bool
     d_images += (ptrdiff_t)f0 * frame_stride;
     d_kps += (size_t)f0 * cap_per_frame; d_desc += (size_t)f0 * cap_per_frame * 32; d_counts += f0;
     uint8_t* const pyr = ex->d_pyr + (size_t)f0 * G.pyr_bytes;
-    uint8_t* const blur = ex->d_blur + (size_t)f0 * G.blur_bytes;
+    uint8_t* const blur = ex->d_blur ? ex->d_blur + (size_t)f0 * G.blur_bytes : nullptr;
     uint32_t* const cand = ex->d_cand + (size_t)f0 * G.cand_total;
     uint16_t* const cellcnt = ex->d_cellcnt + (size_t)f0 * G.cells.size();
     uint32_t* const keys = ex->d_keys + (size_t)f0 * ex->key_total;
@@ -2900,6 +2902,10 @@ int orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* 
     if (ex->own_blur) {
         // this context's k_describe blurs its windows itself: make the blurred levels of the last batch now
         const Geometry& G = ex->geo;
+        if (!ex->d_blur) {
+            HIP_CHECK(hipMalloc(&ex->d_blur, G.blur_bytes * (size_t)ex->max_batch + 256));
+            HIP_CHECK(hipMemset(ex->d_blur, 0, G.blur_bytes * (size_t)ex->max_batch + 256));
+        }
         dim3 gblur(frame_chunk_grid((unsigned)ex->n_blur_chunks, ex->max_batch));
         if (ex->params.blur_rounding)
             hipLaunchKernelGGL(k_blur<1>, gblur, dim3(256), 0, ex->stream, ex->d_pyr, ex->d_blur, (unsigned long long)G.pyr_bytes, (unsigned long long)G.blur_bytes, ex->d_lv, ex->d_blur_chunks, ex->max_batch);
